@@ -1,0 +1,107 @@
+// Shared helpers for the gfx950 kernels: error plumbing, dtype helpers,
+// 16-byte vector access.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "fss.h"
+
+namespace fss {
+
+void set_error(const std::string& msg);
+
+#define FSS_CHECK_HIP(expr)                                                    \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      ::fss::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));     \
+      return 1;                                                                \
+    }                                                                          \
+  } while (0)
+
+#define FSS_REQUIRE(cond, msg)                                                 \
+  do {                                                                         \
+    if (!(cond)) {                                                             \
+      ::fss::set_error(std::string(__func__) + ": " + (msg));                  \
+      return 2;                                                                \
+    }                                                                          \
+  } while (0)
+
+#define FSS_LAUNCH_CHECK()                                                     \
+  do {                                                                         \
+    hipError_t e_ = hipGetLastError();                                         \
+    if (e_ != hipSuccess) {                                                    \
+      ::fss::set_error(std::string(__func__) + " launch: " +                   \
+                       hipGetErrorString(e_));                                 \
+      return 3;                                                                \
+    }                                                                          \
+  } while (0)
+
+typedef unsigned short bf16_t;  // storage type of bfloat16
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __uint_as_float(((unsigned)v) << 16);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  // hipcc lowers the cast to v_cvt_pk_bf16_f32 (round to nearest even).
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+  static constexpr int kPerChunk = 4;  // elements per 16-byte chunk
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int kPerChunk = 8;
+  static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// A 16-byte chunk of T viewed as floats.
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  float v[4];
+  __device__ __forceinline__ void load(const float* p) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct Chunk<bf16_t> {
+  static constexpr int N = 8;
+  float v[8];
+  __device__ __forceinline__ void load(const bf16_t* p) {
+    uint4 t = *reinterpret_cast<const uint4*>(p);
+    unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ __forceinline__ void store(bf16_t* p) const {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == FSS_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == FSS_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+  return v;
+}
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace fss

@@ -1,0 +1,674 @@
+// Bandwidth-bound kernels of the segmentation forward pass (gfx950).
+//
+// All tensors are NHWC.  Kernels are written per 16-byte channel chunk: lane i
+// of a wave touches chunk i of a pixel row, so a wave reads / writes 1 KiB of
+// consecutive bytes whenever a pixel has >= 64 chunks, and whole pixels
+// otherwise.  Arithmetic is float regardless of the storage dtype.
+#include "fss_common.h"
+
+namespace fss {
+
+static constexpr int kBlock = 256;
+static inline unsigned grid_for(size_t work) {
+  size_t g = (work + kBlock - 1) / kBlock;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+// ------------------------------------------------------------- legacy bilinear
+// TF 1.x resize_bilinear source coordinate: in = out_index * scale (float32),
+// lower = floor(in), upper = min(lower + 1, size - 1), lerp = in - lower.
+__device__ __forceinline__ void interp_coord(int o, float scale, int in_size, int& lo, int& hi,
+                                             float& lerp) {
+  const float src = (float)o * scale;
+  const float fl = floorf(src);
+  lo = min((int)fl, in_size - 1);
+  hi = min(lo + 1, in_size - 1);
+  lerp = src - fl;
+}
+static inline float resize_scale(int in_size, int out_size, int align_corners) {
+  if (align_corners && out_size > 1) return (float)(in_size - 1) / (float)(out_size - 1);
+  return (float)in_size / (float)out_size;
+}
+
+// ------------------------------------------------------------------ max pool
+template <typename T>
+__global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                               int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const size_t total = (size_t)N * Ho * Wo * cc;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % cc);
+  size_t p = idx / cc;
+  const int ow = (int)(p % Wo); p /= Wo;
+  const int oh = (int)(p % Ho);
+  const int n = (int)(p / Ho);
+  Chunk<T> best;
+#pragma unroll
+  for (int e = 0; e < E; ++e) best.v[e] = -INFINITY;
+  for (int r = 0; r < k; ++r) {
+    const int ih = oh * stride - pad_t + r;
+    if ((unsigned)ih >= (unsigned)H) continue;
+    for (int s = 0; s < k; ++s) {
+      const int iw = ow * stride - pad_l + s;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      Chunk<T> v;
+      v.load(x + (((size_t)n * H + ih) * W + iw) * C + ch * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) best.v[e] = fmaxf(best.v[e], v.v[e]);
+    }
+  }
+  best.store(y + idx * E);
+}
+
+// ----------------------------------------------------------------- subsample
+template <typename T>
+__global__ void subsample_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W,
+                                 int C, int stride, int Ho, int Wo) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const size_t total = (size_t)N * Ho * Wo * cc;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % cc);
+  size_t p = idx / cc;
+  const int ow = (int)(p % Wo); p /= Wo;
+  const int oh = (int)(p % Ho);
+  const int n = (int)(p / Ho);
+  const uint4 v = *reinterpret_cast<const uint4*>(
+      x + (((size_t)n * H + (size_t)oh * stride) * W + (size_t)ow * stride) * C + ch * E);
+  *reinterpret_cast<uint4*>(y + idx * E) = v;
+}
+
+// ------------------------------------------------------------ avg pool (bins)
+// One block per (image, bin); threadIdx.x walks channel chunks, threadIdx.y
+// splits the window's pixels; partial sums meet in LDS.
+template <typename T, int TX, int TY>
+__global__ void avgpool_bins_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C,
+                                    int kh, int kw, int bh, int bw) {
+  constexpr int E = Chunk<T>::N;
+  __shared__ float part[TY][TX * E];
+  const int bin = blockIdx.x;
+  const int bx = bin % bw;
+  const int by = (bin / bw) % bh;
+  const int n = bin / (bw * bh);
+  const int cc = C / E;
+  const int npix = kh * kw;
+  const float inv = 1.f / (float)npix;
+  for (int ch0 = blockIdx.y * TX; ch0 < cc; ch0 += gridDim.y * TX) {
+    const int ch = ch0 + threadIdx.x;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    if (ch < cc) {
+      for (int p = threadIdx.y; p < npix; p += TY) {
+        const int ih = by * kh + p / kw;
+        const int iw = bx * kw + p % kw;
+        Chunk<T> v;
+        v.load(x + (((size_t)n * H + ih) * W + iw) * C + ch * E);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += v.v[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) part[threadIdx.y][threadIdx.x * E + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.y == 0 && ch < cc) {
+      Chunk<T> o;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < TY; ++t) s += part[t][threadIdx.x * E + e];
+        o.v[e] = s * inv;
+      }
+      o.store(y + (((size_t)n * bh + by) * bw + bx) * C + ch * E);
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------ bilinear resize
+template <typename T, bool VEC>
+__global__ void resize_bilinear_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H,
+                                       int W, int C, int Ho, int Wo, int y_ld, float sh,
+                                       float sw) {
+  constexpr int E = VEC ? Chunk<T>::N : 1;
+  const int cc = C / E;
+  const size_t total = (size_t)N * Ho * Wo * cc;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % cc);
+  size_t p = idx / cc;
+  const int ow = (int)(p % Wo); p /= Wo;
+  const int oh = (int)(p % Ho);
+  const int n = (int)(p / Ho);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  interp_coord(oh, sh, H, y0, y1, ly);
+  interp_coord(ow, sw, W, x0, x1, lx);
+  const T* b = x + (size_t)n * H * W * C + ch * E;
+  T* out = y + (((size_t)n * Ho + oh) * Wo + ow) * y_ld + ch * E;
+  if constexpr (VEC) {
+    Chunk<T> tl, tr, bl, br, o;
+    tl.load(b + ((size_t)y0 * W + x0) * C);
+    tr.load(b + ((size_t)y0 * W + x1) * C);
+    bl.load(b + ((size_t)y1 * W + x0) * C);
+    br.load(b + ((size_t)y1 * W + x1) * C);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float top = tl.v[e] + (tr.v[e] - tl.v[e]) * lx;
+      const float bot = bl.v[e] + (br.v[e] - bl.v[e]) * lx;
+      o.v[e] = top + (bot - top) * ly;
+    }
+    o.store(out);
+  } else {
+    const float tl = ElemTraits<T>::load(b + ((size_t)y0 * W + x0) * C);
+    const float tr = ElemTraits<T>::load(b + ((size_t)y0 * W + x1) * C);
+    const float bl = ElemTraits<T>::load(b + ((size_t)y1 * W + x0) * C);
+    const float br = ElemTraits<T>::load(b + ((size_t)y1 * W + x1) * C);
+    const float top = tl + (tr - tl) * lx;
+    const float bot = bl + (br - bl) * lx;
+    ElemTraits<T>::store(out, top + (bot - top) * ly);
+  }
+}
+
+// ---------------------------------------------------- pyramid upsample + add
+struct PyramidArgs {
+  const void* p[8];
+  int bh[8], bw[8];
+  float sh[8], sw[8];
+  int levels;
+};
+
+template <typename T>
+__global__ void pyramid_add_kernel(const T* __restrict__ x, T* __restrict__ y, PyramidArgs a, int N,
+                                   int H, int W, int C) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const size_t total = (size_t)N * H * W * cc;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % cc);
+  size_t p = idx / cc;
+  const int ow = (int)(p % W); p /= W;
+  const int oh = (int)(p % H);
+  const int n = (int)(p / H);
+  Chunk<T> acc;
+  acc.load(x + idx * E);
+  for (int l = 0; l < a.levels; ++l) {
+    const int bh = a.bh[l], bw = a.bw[l];
+    int y0, y1, x0, x1;
+    float ly, lx;
+    interp_coord(oh, a.sh[l], bh, y0, y1, ly);
+    interp_coord(ow, a.sw[l], bw, x0, x1, lx);
+    const T* b = reinterpret_cast<const T*>(a.p[l]) + (size_t)n * bh * bw * C + ch * E;
+    Chunk<T> tl, tr, bl, br;
+    tl.load(b + ((size_t)y0 * bw + x0) * C);
+    tr.load(b + ((size_t)y0 * bw + x1) * C);
+    bl.load(b + ((size_t)y1 * bw + x0) * C);
+    br.load(b + ((size_t)y1 * bw + x1) * C);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float top = tl.v[e] + (tr.v[e] - tl.v[e]) * lx;
+      const float bot = bl.v[e] + (br.v[e] - bl.v[e]) * lx;
+      acc.v[e] += top + (bot - top) * ly;
+    }
+  }
+  acc.store(y + idx * E);
+}
+
+// ------------------------------------------------------------------- add+act
+template <typename T>
+__global__ void add_act_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y,
+                               size_t chunks, int act) {
+  constexpr int E = Chunk<T>::N;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= chunks) return;
+  Chunk<T> va, vb;
+  va.load(a + idx * E);
+  vb.load(b + idx * E);
+#pragma unroll
+  for (int e = 0; e < E; ++e) va.v[e] = apply_act(va.v[e] + vb.v[e], act);
+  va.store(y + idx * E);
+}
+
+// ------------------------------------------------------------- channel copy
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld,
+                                     size_t pixels, int C) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pixels * cc) return;
+  const int ch = (int)(idx % cc);
+  const size_t p = idx / cc;
+  *reinterpret_cast<uint4*>(y + p * y_ld + ch * E) =
+      *reinterpret_cast<const uint4*>(x + p * x_ld + ch * E);
+}
+
+// ---------------------------------------------------------------- preprocess
+struct PreArgs { float mean[3], scale[3]; };
+
+template <typename T>
+__global__ void preprocess_kernel(const uint8_t* __restrict__ x, T* __restrict__ y, int N, int H,
+                                  int W, int Ho, int Wo, int Cout, PreArgs a) {
+  const size_t total = (size_t)N * Ho * Wo;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  size_t p = idx;
+  const int ow = (int)(p % Wo); p /= Wo;
+  const int oh = (int)(p % Ho);
+  const int n = (int)(p / Ho);
+  float v[3] = {0.f, 0.f, 0.f};
+  if (oh < H && ow < W) {
+    const uint8_t* s = x + (((size_t)n * H + oh) * W + ow) * 3;
+    v[0] = (float)s[0]; v[1] = (float)s[1]; v[2] = (float)s[2];
+  }
+  T* out = y + idx * Cout;
+  if (Cout == Chunk<T>::N) {  // one 16-byte store per pixel
+    Chunk<T> o;
+#pragma unroll
+    for (int c = 0; c < Chunk<T>::N; ++c) o.v[c] = c < 3 ? (v[c] - a.mean[c]) * a.scale[c] : 0.f;
+    o.store(out);
+    return;
+  }
+  for (int c = 0; c < Cout; ++c) {
+    const float o = c < 3 ? (v[c] - a.mean[c]) * a.scale[c] : 0.f;
+    ElemTraits<T>::store(out + c, o);
+  }
+}
+
+// ------------------------------------------------------- upsample + argmax
+template <int MAXC>
+__global__ void upsample_argmax_kernel(const float* __restrict__ x, uint8_t* __restrict__ labels,
+                                       float* __restrict__ logits_out, int N, int H, int W, int C,
+                                       int Ho, int Wo, float sh, float sw) {
+  const size_t total = (size_t)N * Ho * Wo;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  size_t p = idx;
+  const int ow = (int)(p % Wo); p /= Wo;
+  const int oh = (int)(p % Ho);
+  const int n = (int)(p / Ho);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  interp_coord(oh, sh, H, y0, y1, ly);
+  interp_coord(ow, sw, W, x0, x1, lx);
+  const float* b = x + (size_t)n * H * W * C;
+  const float* ptl = b + ((size_t)y0 * W + x0) * C;
+  const float* ptr = b + ((size_t)y0 * W + x1) * C;
+  const float* pbl = b + ((size_t)y1 * W + x0) * C;
+  const float* pbr = b + ((size_t)y1 * W + x1) * C;
+  float best = -INFINITY;
+  int arg = 0;
+  for (int c = 0; c < C; ++c) {
+    const float tl = ptl[c], tr = ptr[c], bl = pbl[c], br = pbr[c];
+    const float top = tl + (tr - tl) * lx;
+    const float bot = bl + (br - bl) * lx;
+    const float v = top + (bot - top) * ly;
+    if (logits_out) logits_out[idx * C + c] = v;
+    if (v > best || c == 0) { best = v; arg = c; }
+  }
+  labels[idx] = (uint8_t)arg;
+}
+
+// ----------------------------------------------------------------- label LUT
+__global__ void label_lut_kernel(const uint8_t* __restrict__ labels, float* __restrict__ y,
+                                 const float* __restrict__ table, int N, int H, int W, int Ho,
+                                 int Wo, int CH, int num_classes) {
+  const size_t total = (size_t)N * Ho * Wo;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  size_t p = idx;
+  const int ow = (int)(p % Wo); p /= Wo;
+  const int oh = (int)(p % Ho);
+  const int n = (int)(p / Ho);
+  int l = labels[((size_t)n * H + oh) * W + ow];
+  l = min(l, num_classes - 1);
+  for (int c = 0; c < CH; ++c) y[idx * CH + c] = table[l * CH + c];
+}
+
+// ---------------------------------------------------------- confusion matrix
+// Per-wave private histograms in LDS (int32), flushed once per block with
+// 64-bit global atomics.  A thread folds runs of equal (label, pred) pairs
+// before touching LDS, which removes most same-address LDS atomics on label
+// maps made of large uniform regions.
+__global__ void confusion_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ lab,
+                                 size_t count, int nc, int ignore,
+                                 unsigned long long* __restrict__ cm) {
+  extern __shared__ unsigned int hist[];  // [waves][nc*nc]
+  const int cells = nc * nc;
+  const int waves = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < cells * waves; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  unsigned int* mine = hist + (threadIdx.x >> 6) * cells;
+  constexpr int PER = 16;  // consecutive pixels per thread per step
+  const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+  for (size_t base = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * PER; base < count;
+       base += nthreads * PER) {
+    int run_key = -1;
+    unsigned run_len = 0;
+    const size_t end = base + PER < count ? base + PER : count;
+    for (size_t i = base; i < end; ++i) {
+      const int l = lab[i];
+      int key = -1;
+      if (l != ignore) {
+        const int pr = pred[i];
+        if (l < nc && pr < nc) key = l * nc + pr;
+      }
+      if (key == run_key) {
+        ++run_len;
+      } else {
+        if (run_key >= 0) atomicAdd(&mine[run_key], run_len);
+        run_key = key;
+        run_len = 1;
+      }
+    }
+    if (run_key >= 0) atomicAdd(&mine[run_key], run_len);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+    unsigned long long s = 0;
+    for (int w = 0; w < waves; ++w) s += hist[w * cells + i];
+    if (s) atomicAdd(&cm[i], s);
+  }
+}
+
+// ------------------------------------------------------------ depthwise conv
+template <typename T>
+__global__ void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                              const float* __restrict__ bias, T* __restrict__ y, int N, int H, int W,
+                              int C, int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                              int Ho, int Wo, int act) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const size_t total = (size_t)N * Ho * Wo * cc;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % cc);
+  size_t p = idx / cc;
+  const int ow = (int)(p % Wo); p /= Wo;
+  const int oh = (int)(p % Ho);
+  const int n = (int)(p / Ho);
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  for (int r = 0; r < kh; ++r) {
+    const int ih = oh * stride - pad_t + r * dil;
+    if ((unsigned)ih >= (unsigned)H) continue;
+    for (int s = 0; s < kw; ++s) {
+      const int iw = ow * stride - pad_l + s * dil;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      Chunk<T> v;
+      v.load(x + (((size_t)n * H + ih) * W + iw) * C + ch * E);
+      const float* wp = w + (size_t)(r * kw + s) * C + ch * E;
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = fmaf(v.v[e], wp[e], acc[e]);
+    }
+  }
+  Chunk<T> o;
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+    o.v[e] = apply_act(acc[e] + (bias ? bias[ch * E + e] : 0.f), act);
+  o.store(y + idx * E);
+}
+
+}  // namespace fss
+
+using namespace fss;
+
+#define FSS_DTYPE_OK(dt) FSS_REQUIRE((dt) == FSS_F32 || (dt) == FSS_BF16, "bad dtype")
+#define FSS_CHUNK_OK(c, dt)                                                      \
+  FSS_REQUIRE((c) > 0 && (c) % ((dt) == FSS_F32 ? 4 : 8) == 0,                   \
+              "channel count must be a multiple of 16 bytes of elements")
+#define FSS_ALIGNED(p) FSS_REQUIRE(((uintptr_t)(p) & 15) == 0, "unaligned pointer")
+
+extern "C" {
+
+int fss_maxpool_nhwc(const void* x, void* y, int n, int h, int wd, int c, int k, int stride,
+                     int pad_top, int pad_left, int ho, int wo, int dtype, void* stream) {
+  FSS_REQUIRE(x && y, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_CHUNK_OK(c, dtype);
+  FSS_ALIGNED(x); FSS_ALIGNED(y);
+  FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0 && k > 0 && stride > 0, "bad shape");
+  // every window must contain at least one real pixel
+  FSS_REQUIRE(pad_top >= 0 && pad_left >= 0 && pad_top < k && pad_left < k, "bad padding");
+  FSS_REQUIRE((long long)(ho - 1) * stride - pad_top < h && (long long)(wo - 1) * stride - pad_left < wd,
+              "output size exceeds the input");
+  const size_t total = (size_t)n * ho * wo * (c / (dtype == FSS_F32 ? 4 : 8));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const float*)x, (float*)y, n, h, wd, c, k, stride, pad_top, pad_left, ho, wo);
+  else
+    hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const bf16_t*)x, (bf16_t*)y, n, h, wd, c, k, stride, pad_top, pad_left, ho, wo);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_subsample_nhwc(const void* x, void* y, int n, int h, int wd, int c, int stride, int ho,
+                       int wo, int dtype, void* stream) {
+  FSS_REQUIRE(x && y, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_CHUNK_OK(c, dtype);
+  FSS_ALIGNED(x); FSS_ALIGNED(y);
+  FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0 && stride > 0, "bad shape");
+  FSS_REQUIRE((long long)(ho - 1) * stride < h && (long long)(wo - 1) * stride < wd,
+              "output size exceeds the input");
+  const size_t total = (size_t)n * ho * wo * (c / (dtype == FSS_F32 ? 4 : 8));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL(subsample_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const float*)x, (float*)y, n, h, wd, c, stride, ho, wo);
+  else
+    hipLaunchKernelGGL(subsample_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const bf16_t*)x, (bf16_t*)y, n, h, wd, c, stride, ho, wo);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_avgpool_bins_nhwc(const void* x, void* y, int n, int h, int wd, int c, int kh, int kw,
+                          int bh, int bw, int dtype, void* stream) {
+  FSS_REQUIRE(x && y, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_CHUNK_OK(c, dtype);
+  FSS_ALIGNED(x); FSS_ALIGNED(y);
+  FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && kh > 0 && kw > 0 && bh > 0 && bw > 0, "bad shape");
+  FSS_REQUIRE((long long)bh * kh <= h && (long long)bw * kw <= wd, "bins exceed the input");
+  constexpr int TX = 16, TY = 16;
+  const int cc = c / (dtype == FSS_F32 ? 4 : 8);
+  dim3 grid((unsigned)(n * bh * bw), (unsigned)ceil_div(cc, TX));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL((avgpool_bins_kernel<float, TX, TY>), grid, dim3(TX, TY), 0, s,
+                       (const float*)x, (float*)y, h, wd, c, kh, kw, bh, bw);
+  else
+    hipLaunchKernelGGL((avgpool_bins_kernel<bf16_t, TX, TY>), grid, dim3(TX, TY), 0, s,
+                       (const bf16_t*)x, (bf16_t*)y, h, wd, c, kh, kw, bh, bw);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_resize_bilinear_nhwc(const void* x, void* y, int n, int h, int wd, int c, int ho, int wo,
+                             int y_ld, int align_corners, int dtype, void* stream) {
+  FSS_REQUIRE(x && y, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && c > 0 && ho > 0 && wo > 0, "bad shape");
+  FSS_REQUIRE(y_ld >= c, "y_ld < c");
+  const float sh = resize_scale(h, ho, align_corners), sw = resize_scale(wd, wo, align_corners);
+  const int e = dtype == FSS_F32 ? 4 : 8;
+  const bool vec = (c % e == 0) && (y_ld % e == 0) && (((uintptr_t)x & 15) == 0) &&
+                   (((uintptr_t)y & 15) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)n * ho * wo * (vec ? c / e : c);
+#define FSS_RESIZE(T, V)                                                                        \
+  hipLaunchKernelGGL((resize_bilinear_kernel<T, V>), dim3(grid_for(total)), dim3(kBlock), 0, s, \
+                     (const T*)x, (T*)y, n, h, wd, c, ho, wo, y_ld, sh, sw)
+  if (dtype == FSS_F32) { if (vec) FSS_RESIZE(float, true); else FSS_RESIZE(float, false); }
+  else { if (vec) FSS_RESIZE(bf16_t, true); else FSS_RESIZE(bf16_t, false); }
+#undef FSS_RESIZE
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_pyramid_add_nhwc(const void* x, const void* const* p, const int* bh, const int* bw,
+                         int levels, void* y, int n, int h, int wd, int c, int dtype,
+                         void* stream) {
+  FSS_REQUIRE(x && y && p && bh && bw, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_CHUNK_OK(c, dtype);
+  FSS_ALIGNED(x); FSS_ALIGNED(y);
+  FSS_REQUIRE(levels >= 0 && levels <= 8, "at most 8 pyramid levels");
+  FSS_REQUIRE(n > 0 && h > 0 && wd > 0, "bad shape");
+  PyramidArgs a;
+  a.levels = levels;
+  for (int l = 0; l < 8; ++l) { a.p[l] = nullptr; a.bh[l] = a.bw[l] = 1; a.sh[l] = a.sw[l] = 0.f; }
+  for (int l = 0; l < levels; ++l) {
+    FSS_REQUIRE(p[l] != nullptr && bh[l] > 0 && bw[l] > 0, "bad pyramid level");
+    FSS_ALIGNED(p[l]);
+    a.p[l] = p[l]; a.bh[l] = bh[l]; a.bw[l] = bw[l];
+    a.sh[l] = resize_scale(bh[l], h, 1);
+    a.sw[l] = resize_scale(bw[l], wd, 1);
+  }
+  const size_t total = (size_t)n * h * wd * (c / (dtype == FSS_F32 ? 4 : 8));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL(pyramid_add_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const float*)x, (float*)y, a, n, h, wd, c);
+  else
+    hipLaunchKernelGGL(pyramid_add_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const bf16_t*)x, (bf16_t*)y, a, n, h, wd, c);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_add_act(const void* a, const void* b, void* y, size_t count, int act, int dtype,
+                void* stream) {
+  FSS_REQUIRE(a && b && y, "null argument");
+  FSS_DTYPE_OK(dtype);
+  const int e = dtype == FSS_F32 ? 4 : 8;
+  FSS_REQUIRE(count > 0 && count % e == 0, "count must be a multiple of 16 bytes of elements");
+  FSS_ALIGNED(a); FSS_ALIGNED(b); FSS_ALIGNED(y);
+  const size_t chunks = count / e;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL(add_act_kernel<float>, dim3(grid_for(chunks)), dim3(kBlock), 0, s,
+                       (const float*)a, (const float*)b, (float*)y, chunks, act);
+  else
+    hipLaunchKernelGGL(add_act_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(kBlock), 0, s,
+                       (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, chunks, act);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_copy_channels(const void* x, int x_ld, void* y, int y_ld, size_t pixels, int c, int dtype,
+                      void* stream) {
+  FSS_REQUIRE(x && y, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_CHUNK_OK(c, dtype);
+  const int e = dtype == FSS_F32 ? 4 : 8;
+  FSS_REQUIRE(x_ld >= c && y_ld >= c && x_ld % e == 0 && y_ld % e == 0, "bad pixel stride");
+  FSS_ALIGNED(x); FSS_ALIGNED(y);
+  FSS_REQUIRE(pixels > 0, "bad shape");
+  const size_t total = pixels * (c / e);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const float*)x, x_ld, (float*)y, y_ld, pixels, c);
+  else
+    hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const bf16_t*)x, x_ld, (bf16_t*)y, y_ld, pixels, c);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho, int wo, int c_out,
+                      const float* mean3, const float* scale3, int dtype, void* stream) {
+  FSS_REQUIRE(x && y && mean3 && scale3, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho >= h && wo >= wd, "bad shape");
+  FSS_REQUIRE(c_out >= 3 && c_out <= 64, "c_out must be in [3, 64]");
+  PreArgs a;
+  for (int i = 0; i < 3; ++i) { a.mean[i] = mean3[i]; a.scale[i] = scale3[i]; }
+  const size_t total = (size_t)n * ho * wo;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL(preprocess_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, x,
+                       (float*)y, n, h, wd, ho, wo, c_out, a);
+  else
+    hipLaunchKernelGGL(preprocess_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, x,
+                       (bf16_t*)y, n, h, wd, ho, wo, c_out, a);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_upsample_argmax(const float* logits, uint8_t* labels, float* logits_out, int n, int h,
+                        int wd, int c, int ho, int wo, void* stream) {
+  FSS_REQUIRE(logits && labels, "null argument");
+  FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0, "bad shape");
+  FSS_REQUIRE(c > 0 && c <= 256, "class count must be in [1, 256]");
+  const float sh = resize_scale(h, ho, 1), sw = resize_scale(wd, wo, 1);
+  const size_t total = (size_t)n * ho * wo;
+  hipLaunchKernelGGL(upsample_argmax_kernel<0>, dim3(grid_for(total)), dim3(kBlock), 0,
+                     (hipStream_t)stream, logits, labels, logits_out, n, h, wd, c, ho, wo, sh, sw);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_label_lut(const uint8_t* labels, float* y, const float* table, int n, int h, int wd,
+                  int ho, int wo, int channels, int num_classes, void* stream) {
+  FSS_REQUIRE(labels && y && table, "null argument");
+  FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0 && ho <= h && wo <= wd, "bad shape");
+  FSS_REQUIRE(channels > 0 && num_classes > 0 && num_classes <= 256, "bad table");
+  const size_t total = (size_t)n * ho * wo;
+  hipLaunchKernelGGL(label_lut_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream,
+                     labels, y, table, n, h, wd, ho, wo, channels, num_classes);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_confusion_accumulate(const uint8_t* pred, const uint8_t* labels, size_t count,
+                             int num_classes, int ignore_label, int64_t* cm, void* stream) {
+  FSS_REQUIRE(pred && labels && cm, "null argument");
+  FSS_REQUIRE(num_classes > 0 && num_classes <= 64, "num_classes must be in [1, 64]");
+  if (count == 0) return 0;
+  const int threads = 256;
+  const size_t smem = (size_t)(threads / 64) * num_classes * num_classes * sizeof(unsigned int);
+  size_t blocks = (count + (size_t)threads * 16 - 1) / ((size_t)threads * 16);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(threads), smem,
+                     (hipStream_t)stream, pred, labels, count, num_classes, ignore_label,
+                     (unsigned long long*)cm);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y, int n, int h,
+                      int wd, int c, int kh, int kw, int stride, int dilation, int pad_top,
+                      int pad_left, int ho, int wo, int act, int dtype, void* stream) {
+  FSS_REQUIRE(x && w && y, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_CHUNK_OK(c, dtype);
+  FSS_ALIGNED(x); FSS_ALIGNED(y);
+  FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0, "bad shape");
+  FSS_REQUIRE(kh > 0 && kw > 0 && stride > 0 && dilation > 0 && pad_top >= 0 && pad_left >= 0,
+              "bad filter");
+  const size_t total = (size_t)n * ho * wo * (c / (dtype == FSS_F32 ? 4 : 8));
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL(dwconv_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const float*)x, w, bias, (float*)y, n, h, wd, c, kh, kw, stride, dilation,
+                       pad_top, pad_left, ho, wo, act);
+  else
+    hipLaunchKernelGGL(dwconv_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const bf16_t*)x, w, bias, (bf16_t*)y, n, h, wd, c, kh, kw, stride, dilation,
+                       pad_top, pad_left, ho, wo, act);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,640 @@
+"""Lowers an `fss.graph` graph to launches of the gfx950 kernels and runs it.
+
+compile = (1) copy the live sub-graph into a private node list and rewrite it,
+(2) lower node by node with fusion, assigning device buffers, (3) fold batch
+norm into / pack the weights, (4) one eager run, (5) capture the launch
+sequence into a hipGraph that `launch()` replays.
+
+Fusions (each replaces a chain of reference ops by one kernel):
+  * placeholder -> pad_to_bounding_box -> to_float -> channel affine   => fss_preprocess_u8
+  * conv2d + folded batch norm + activation [+ add(other) [+ relu]]    => fss_conv2d_nhwc
+  * x + resize(avg_pool(x)) + ... of the fast pyramid pooling module   => fss_pyramid_add_nhwc
+  * resize(logits) -> argmax                                           => fss_upsample_argmax
+  * lut -> crop                                                        => fss_label_lut
+Rewrites:
+  * a same-size resize is dropped;
+  * the 1x1 biased classifier is moved in front of the bilinear zoom that
+    feeds it (exact up to rounding: bilinear weights sum to one), so the zoom
+    runs on num_classes channels instead of hundreds.
+Device memory, streams and host<->device copies go through torch; all
+arithmetic goes through libfss_gfx950.so.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from fss import _lib
+from fss._lib import lib, check
+
+_TORCH_DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'u8': torch.uint8}
+_CODE = {'f32': _lib.F32, 'bf16': _lib.BF16}
+_EPC = {'f32': 4, 'bf16': 8}
+_ESZ = {'f32': 4, 'bf16': 2, 'u8': 1}
+
+
+def f32_to_bf16_bits(a):
+    """float32 ndarray -> uint16 ndarray of bfloat16 bits (round to nearest even)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return u.astype(np.uint16)
+
+
+class LNode(object):
+    """Private, mutable copy of a graph node used during lowering."""
+
+    def __init__(self, kind, inputs, attrs, shape, dtype):
+        self.kind, self.inputs, self.attrs = kind, list(inputs), dict(attrs)
+        self.shape, self.dtype = tuple(shape), dtype
+        self.pos = -1
+        self.consumers = []
+        self.is_output = False
+
+
+class Val(object):
+    """A materialised tensor: torch buffer + logical shape + physical layout."""
+
+    def __init__(self, buf, shape, dt, phys_c=None, ld=None, coff=0):
+        self.buf = buf              # torch tensor [n, H, W, ld] (may be wider / larger than shape)
+        self.shape = tuple(shape)   # logical (n, h, w, c)
+        self.dt = dt                # 'f32' | 'bf16' | 'u8'
+        self.phys_c = phys_c if phys_c is not None else shape[3]
+        self.ld = ld if ld is not None else self.phys_c   # pixel stride in elements
+        self.coff = coff            # channel offset inside buf
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.coff * self.buf.element_size()
+
+    @property
+    def dense(self):
+        return self.ld == self.phys_c and self.coff == 0
+
+
+class Step(object):
+    __slots__ = ('kind', 'name', 'fn', 'args', 'flops', 'bytes', 'keep')
+
+    def __init__(self, kind, name, fn, args, flops=0, nbytes=0, keep=None):
+        self.kind, self.name, self.fn, self.args = kind, name, fn, args
+        self.flops, self.bytes, self.keep = flops, nbytes, keep
+
+
+class CompiledGraph(object):
+    """Executable form of a graph for fixed shapes, weights and compute dtype.
+
+    outputs: graph tensors to make fetchable.  dtype: 'float32' | 'bfloat16'
+    (storage + MFMA input type of activations; logits and everything after the
+    classifier stay float32)."""
+
+    def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
+                 commute_classifier=True, use_hip_graph=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
+        self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+        self.weights = weights
+        self.outputs = list(outputs)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.sh = ctypes.c_void_p(self.stream.cuda_stream)
+        self.steps = []
+        self.vals = {}          # LNode -> Val
+        self.lazy = {}          # LNode -> (tag, info..., materialise closure)
+        self.keepalive = []     # device-side constants (packed weights, biases, tables)
+        self.input_val = None
+        self.graph_exec = None
+        self.param_bytes = 0
+        with torch.cuda.device(self.device):
+            self._import(graph, outputs, commute_classifier)
+            self._lower()
+            torch.cuda.synchronize(self.device)   # constants were uploaded on torch's stream
+            self.run_eager()
+            self.sync()
+            if use_hip_graph:
+                self._capture()
+
+    # ---------------------------------------------------- import + rewrites
+    def _import(self, graph, outputs, commute_classifier):
+        live, stack = set(), [t.node.index for t in outputs]
+        while stack:
+            i = stack.pop()
+            if i not in live:
+                live.add(i)
+                stack.extend(t.node.index for t in graph.nodes[i].inputs)
+        m = {}
+        order = []
+        for i in sorted(live):
+            nd = graph.nodes[i]
+            ln = LNode(nd.kind, [m[t.node.index] for t in nd.inputs], nd.attrs,
+                       nd.output.shape, nd.output.dtype)
+            m[i] = ln
+            order.append(ln)
+        self.out_nodes = {t.node.index: m[t.node.index] for t in outputs}
+
+        def replace_uses(old, new):
+            for ln in order:
+                ln.inputs = [new if x is old else x for x in ln.inputs]
+            for k, v in self.out_nodes.items():
+                if v is old:
+                    self.out_nodes[k] = new
+
+        def n_uses(x):
+            return sum(1 for ln in order for y in ln.inputs if y is x) + \
+                sum(1 for v in self.out_nodes.values() if v is x)
+
+        # same-size resize -> identity
+        for ln in list(order):
+            if ln.kind == 'resize' and ln.shape[1:3] == ln.inputs[0].shape[1:3]:
+                replace_uses(ln, ln.inputs[0])
+                order.remove(ln)
+        # classifier in front of the zoom that feeds it
+        if commute_classifier:
+            for ln in list(order):
+                a = ln.attrs
+                if not (ln.kind == 'conv2d' and a['bn'] is None and a['activation'] is None
+                        and (a['kh'], a['kw'], a['stride'], a['rate']) == (1, 1, 1, 1)):
+                    continue
+                r = ln.inputs[0]
+                if not (r.kind == 'resize' and r.attrs['align_corners'] and n_uses(r) == 1):
+                    continue
+                x = r.inputs[0]
+                conv = LNode('conv2d', [x], a, x.shape[:3] + (ln.shape[3],), ln.dtype)
+                zoom = LNode('resize', [conv], r.attrs, ln.shape, ln.dtype)
+                at = order.index(ln)
+                order[at:at + 1] = [conv, zoom]
+                order.remove(r)
+                replace_uses(ln, zoom)
+        self.order = order
+        for p, ln in enumerate(order):
+            ln.pos = p
+            ln.consumers = []
+        for ln in order:
+            for x in ln.inputs:
+                x.consumers.append(ln)
+        for v in self.out_nodes.values():
+            v.is_output = True
+
+    # ------------------------------------------------------------------ utils
+    def _alloc(self, shape, dt, phys_c=None):
+        n, h, w, c = shape
+        return torch.empty((n, h, w, phys_c if phys_c is not None else c),
+                           dtype=_TORCH_DT[dt], device=self.device)
+
+    def _dev_f32(self, arr):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
+        self.keepalive.append(t)
+        return t
+
+    def _val(self, ln):
+        """Value of a node, materialising a deferred one on first real use."""
+        if ln not in self.vals and ln in self.lazy:
+            self.lazy.pop(ln)[-1]()
+        return self.vals[ln]
+
+    @staticmethod
+    def _only_consumer(ln, kind):
+        if ln.is_output or len(ln.consumers) != 1 or ln.consumers[0].kind != kind:
+            return None
+        return ln.consumers[0]
+
+    def _emit(self, kind, name, fname, args, flops=0, nbytes=0, keep=None):
+        self.steps.append(Step(kind, name, getattr(lib, fname), args, flops, nbytes, keep))
+
+    # --------------------------------------------------------------- lowering
+    def _lower(self):
+        # concat buffers first: resize producers with one consumer write in place
+        self.placement = {}
+        for ln in self.order:
+            if ln.kind != 'concat':
+                continue
+            buf = self._alloc(ln.shape, self.dt)
+            self.vals[ln] = Val(buf, ln.shape, self.dt)
+            off = 0
+            for src in ln.inputs:
+                if (src.kind == 'resize' and not src.is_output and len(src.consumers) == 1
+                        and off % _EPC[self.dt] == 0):
+                    self.placement[src] = (buf, off, ln.shape[3])
+                off += src.shape[3]
+        self.fused = set()
+        handlers = {
+            'placeholder': self._l_placeholder, 'pad_to_bbox': self._l_image_op,
+            'to_float': self._l_image_op, 'affine': self._l_affine,
+            'conv2d': self._l_conv, 'depthwise': self._l_depthwise,
+            'max_pool': self._l_maxpool, 'avg_pool': self._l_avgpool,
+            'resize': self._l_resize, 'add': self._l_add, 'relu': self._l_relu,
+            'concat': self._l_concat, 'argmax': self._l_argmax, 'lut': self._l_lut,
+            'crop': self._l_crop,
+        }
+        for ln in self.order:
+            if ln in self.fused:
+                continue
+            handlers[ln.kind](ln)
+        for ln in self.out_nodes.values():
+            self._val(ln)
+
+    # ---- input image chain
+    def _l_placeholder(self, ln):
+        if self.input_val is not None:
+            raise NotImplementedError('a graph may have one placeholder')
+        if ln.dtype != 'uint8' or ln.shape[3] != 3:
+            raise NotImplementedError('placeholders must be uint8 images with 3 channels')
+        buf = torch.zeros(ln.shape, dtype=torch.uint8, device=self.device)
+        self.input_val = Val(buf, ln.shape, 'u8')
+        self.vals[ln] = self.input_val
+        self.image_src = {ln: ln}
+
+    def _l_image_op(self, ln):
+        src = self.image_src.get(ln.inputs[0])
+        if src is None:
+            raise NotImplementedError('%s is only supported on the input image' % ln.kind)
+        self.image_src[ln] = src
+
+    def _l_affine(self, ln):
+        src = self.image_src.get(ln.inputs[0])
+        if src is None:
+            raise NotImplementedError('channel_affine is only supported on the input image')
+        n, ho, wo, c = ln.shape
+        pc = _EPC[self.dt]
+        out = Val(self._alloc(ln.shape, self.dt, phys_c=pc), ln.shape, self.dt, phys_c=pc)
+        self.vals[ln] = out
+        x = self.vals[src]
+        _, h, w, _ = x.shape
+        mean = (ctypes.c_float * 3)(*ln.attrs['mean'])
+        scale = (ctypes.c_float * 3)(*ln.attrs['scale'])
+        self._emit('preprocess', 'preprocess', 'fss_preprocess_u8',
+                   (x.ptr, out.ptr, n, h, w, ho, wo, pc, mean, scale, _CODE[self.dt], self.sh),
+                   nbytes=n * h * w * 3 + n * ho * wo * pc * _ESZ[self.dt], keep=(mean, scale))
+
+    # ---- convolutions
+    def _fold_bn(self, a, cout):
+        W = self.weights
+        if a['bn'] is not None:
+            bn = a['bn']
+            scale = 1.0 / np.sqrt(W[bn['var']].astype(np.float64) + bn['epsilon'])
+            if bn['gamma'] is not None:
+                scale = scale * W[bn['gamma']].astype(np.float64)
+            bias = -W[bn['mean']].astype(np.float64) * scale
+            if bn['beta'] is not None:
+                bias = bias + W[bn['beta']].astype(np.float64)
+            return scale, bias
+        return np.ones(cout, np.float64), W[a['biases']].astype(np.float64)
+
+    def _l_conv(self, ln):
+        a = ln.attrs
+        x = self._val(ln.inputs[0])
+        if not x.dense:
+            raise NotImplementedError('conv input must be dense')
+        n, h, w, cin = x.shape
+        _, ho, wo, cout = ln.shape
+        kh, kw = a['kh'], a['kw']
+        in_dt = x.dt
+        out_dt = 'f32' if a['biases'] is not None else in_dt    # logits stay float32
+        act = a['activation']
+        res, result = None, ln
+        add = self._only_consumer(ln, 'add')
+        if add is not None and act is None and out_dt == in_dt:
+            other = [y for y in add.inputs if y is not ln]
+            other = other[0] if other else None
+            if other is not None and other.pos < ln.pos:
+                ov = self._val(other)
+                if ov.dt == in_dt:
+                    res, result = ov, add
+                    self.fused.add(add)
+                    relu = self._only_consumer(add, 'relu')
+                    if relu is not None:
+                        act, result = 'relu', relu
+                        self.fused.add(relu)
+        scale, bias = self._fold_bn(a, cout)
+        Wt = self.weights[a['weights']].astype(np.float64) * scale      # [kh,kw,cin,cout]
+        pc = x.phys_c
+        if pc != cin:
+            Wt = np.pad(Wt, ((0, 0), (0, 0), (0, pc - cin), (0, 0)))
+        k_pad, cout_pad = _lib.conv_pack_dims(pc, kh, kw, cout, _CODE[in_dt])
+        Wp = np.zeros((cout_pad, k_pad), np.float32)
+        Wp[:cout, :kh * kw * pc] = Wt.transpose(3, 0, 1, 2).reshape(cout, -1)
+        if in_dt == 'bf16':
+            wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+        else:
+            wdev = torch.from_numpy(Wp).to(self.device)
+        self.keepalive.append(wdev)
+        bdev = self._dev_f32(bias)
+        self.param_bytes += cout * kh * kw * cin * _ESZ[in_dt]
+        out = Val(self._alloc(ln.shape, out_dt), ln.shape, out_dt)
+        self.vals[result] = out
+        if result is not ln:
+            self.vals[ln] = out
+        d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc, cout=cout, kh=kh, kw=kw, stride=a['stride'],
+                          dilation=a['rate'], pad_top=a['pad_top'], pad_left=a['pad_left'],
+                          ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE[in_dt],
+                          out_dtype=_CODE[out_dt], y_ld=out.ld, res_ld=res.ld if res else 0,
+                          k_pad=k_pad, cout_pad=cout_pad)
+        nbytes = ((n * h * w * pc + cout * kh * kw * pc) * _ESZ[in_dt]
+                  + n * ho * wo * cout * _ESZ[out_dt]
+                  + (n * ho * wo * cout * _ESZ[in_dt] if res else 0))
+        self._emit('conv', a['weights'].rsplit('/', 1)[0], 'fss_conv2d_nhwc',
+                   (ctypes.byref(d), x.ptr, wdev.data_ptr(), bdev.data_ptr(),
+                    res.ptr if res else None, out.ptr, self.sh),
+                   flops=2 * n * ho * wo * cout * kh * kw * cin, nbytes=nbytes, keep=d)
+
+    def _l_depthwise(self, ln):
+        a = ln.attrs
+        x = self._val(ln.inputs[0])
+        if not x.dense:
+            raise NotImplementedError('depthwise input must be dense')
+        n, h, w, c = x.shape
+        _, ho, wo, _ = ln.shape
+        scale, bias = self._fold_bn(a, c)
+        Wt = self.weights[a['weights']].astype(np.float64)[:, :, :, 0] * scale   # [kh,kw,c]
+        wdev = self._dev_f32(Wt.reshape(a['kh'] * a['kw'], c))
+        bdev = self._dev_f32(bias)
+        self.param_bytes += a['kh'] * a['kw'] * c * 4
+        out = Val(self._alloc(ln.shape, x.dt), ln.shape, x.dt)
+        self.vals[ln] = out
+        self._emit('depthwise', a['weights'].rsplit('/', 1)[0], 'fss_dwconv2d_nhwc',
+                   (x.ptr, wdev.data_ptr(), bdev.data_ptr(), out.ptr, n, h, w, c, a['kh'], a['kw'],
+                    a['stride'], a['rate'], a['pad_top'], a['pad_left'], ho, wo,
+                    _lib.ACT_CODES[a['activation']], _CODE[x.dt], self.sh),
+                   flops=2 * n * ho * wo * c * a['kh'] * a['kw'],
+                   nbytes=(n * h * w * c + n * ho * wo * c) * _ESZ[x.dt])
+
+    # ---- pooling
+    def _l_maxpool(self, ln):
+        a = ln.attrs
+        x = self._val(ln.inputs[0])
+        if not x.dense:
+            raise NotImplementedError('pool input must be dense')
+        n, h, w, c = x.shape
+        _, ho, wo, _ = ln.shape
+        out = Val(self._alloc(ln.shape, x.dt), ln.shape, x.dt)
+        self.vals[ln] = out
+        if a['k'] == 1:
+            self._emit('subsample', 'subsample', 'fss_subsample_nhwc',
+                       (x.ptr, out.ptr, n, h, w, c, a['stride'], ho, wo, _CODE[x.dt], self.sh),
+                       nbytes=2 * n * ho * wo * c * _ESZ[x.dt])
+        else:
+            self._emit('maxpool', 'max_pool', 'fss_maxpool_nhwc',
+                       (x.ptr, out.ptr, n, h, w, c, a['k'], a['stride'], a['pad_top'],
+                        a['pad_left'], ho, wo, _CODE[x.dt], self.sh),
+                       nbytes=(n * h * w * c + n * ho * wo * c) * _ESZ[x.dt])
+
+    def _l_avgpool(self, ln):
+        a = ln.attrs
+        x = self._val(ln.inputs[0])
+        if not x.dense:
+            raise NotImplementedError('pool input must be dense')
+        n, h, w, c = x.shape
+        _, bh, bw, _ = ln.shape
+        out = Val(self._alloc(ln.shape, x.dt), ln.shape, x.dt)
+        self.vals[ln] = out
+        self._emit('avgpool', 'avg_pool', 'fss_avgpool_bins_nhwc',
+                   (x.ptr, out.ptr, n, h, w, c, a['kh'], a['kw'], bh, bw, _CODE[x.dt], self.sh),
+                   nbytes=(n * bh * a['kh'] * bw * a['kw'] * c + n * bh * bw * c) * _ESZ[x.dt])
+
+    # ---- resize (deferred: fused into its consumer when possible)
+    def _l_resize(self, ln):
+        src = ln.inputs[0]
+        align = ln.attrs['align_corners']
+
+        def materialise():
+            x = self._val(src)
+            if not x.dense:
+                raise NotImplementedError('resize input must be dense')
+            n, h, w, c = x.shape
+            _, ho, wo, _ = ln.shape
+            place = self.placement.get(ln)
+            if place is not None and x.phys_c == c:
+                buf, off, ld = place
+                out = Val(buf, ln.shape, x.dt, phys_c=c, ld=ld, coff=off)
+            else:
+                self.placement.pop(ln, None)
+                out = Val(self._alloc(ln.shape, x.dt, phys_c=x.phys_c), ln.shape, x.dt,
+                          phys_c=x.phys_c)
+            self.vals[ln] = out
+            self._emit('resize', 'resize_bilinear', 'fss_resize_bilinear_nhwc',
+                       (x.ptr, out.ptr, n, h, w, x.phys_c, ho, wo, out.ld, 1 if align else 0,
+                        _CODE[x.dt], self.sh),
+                       nbytes=(n * h * w + n * ho * wo) * x.phys_c * _ESZ[x.dt])
+
+        self.lazy[ln] = ('resize', src, align, materialise)
+
+    # ---- add / relu
+    def _pyramid_term(self, ln, like):
+        """ln is a deferred align_corners resize of a small dense map shaped like `like`?"""
+        d = self.lazy.get(ln)
+        if not d or d[0] != 'resize' or not d[2] or ln.is_output or len(ln.consumers) != 1:
+            return None
+        small = self._val(d[1])
+        if (small.dense and small.dt == self.dt and small.shape[3] % _EPC[small.dt] == 0
+                and small.shape[1] * small.shape[2] <= 256 and ln.shape == like.shape):
+            return small
+        return None
+
+    def _l_add(self, ln):
+        a_n, b_n = ln.inputs
+        term = self._pyramid_term(b_n, a_n)
+        if term is None:
+            term = self._pyramid_term(a_n, b_n)
+            if term is not None:
+                a_n, b_n = b_n, a_n
+        if term is not None:
+            self.lazy.pop(b_n)
+            prev = self.lazy.get(a_n)
+            if prev and prev[0] == 'pyramid' and not a_n.is_output and len(a_n.consumers) == 1:
+                self.lazy.pop(a_n)
+                base, levels = prev[1], prev[2] + [term]
+            else:
+                base, levels = a_n, [term]
+            if len(levels) <= 8:
+                def materialise(base=base, levels=levels):
+                    x = self._val(base)
+                    if not x.dense:
+                        raise NotImplementedError('pyramid base must be dense')
+                    out = Val(self._alloc(ln.shape, x.dt), ln.shape, x.dt)
+                    self.vals[ln] = out
+                    n, h, w, c = x.shape
+                    L = len(levels)
+                    ptrs = (ctypes.c_void_p * L)(*[t.ptr for t in levels])
+                    bh = (ctypes.c_int * L)(*[t.shape[1] for t in levels])
+                    bw = (ctypes.c_int * L)(*[t.shape[2] for t in levels])
+                    self._emit('pyramid', 'pyramid_add', 'fss_pyramid_add_nhwc',
+                               (x.ptr, ptrs, bh, bw, L, out.ptr, n, h, w, c, _CODE[x.dt], self.sh),
+                               nbytes=2 * n * h * w * c * _ESZ[x.dt], keep=(ptrs, bh, bw))
+                self.lazy[ln] = ('pyramid', base, levels, materialise)
+                return
+        a, b = self._val(ln.inputs[0]), self._val(ln.inputs[1])
+        if not (a.dense and b.dense) or a.dt != b.dt or a.phys_c != a.shape[3]:
+            raise NotImplementedError('add needs dense operands of one dtype')
+        act, result = None, ln
+        relu = self._only_consumer(ln, 'relu')
+        if relu is not None:
+            act, result = 'relu', relu
+            self.fused.add(relu)
+        out = Val(self._alloc(ln.shape, a.dt), ln.shape, a.dt)
+        self.vals[result] = out
+        self.vals[ln] = out
+        count = int(np.prod(a.shape))
+        self._emit('add', 'add', 'fss_add_act',
+                   (a.ptr, b.ptr, out.ptr, count, _lib.ACT_CODES[act], _CODE[a.dt], self.sh),
+                   nbytes=3 * count * _ESZ[a.dt])
+
+    def _l_relu(self, ln):
+        raise NotImplementedError('stand-alone relu (not following an add) is not supported')
+
+    # ---- concat
+    def _l_concat(self, ln):
+        out = self.vals[ln]
+        n, h, w, ctot = out.shape
+        off = 0
+        for src in ln.inputs:
+            c = src.shape[3]
+            x = self._val(src)      # placed producers materialise straight into `out`
+            if not (x.buf is out.buf and x.coff == off):
+                if x.dt != out.dt or x.phys_c != c:
+                    raise NotImplementedError('concat inputs must share the compute dtype')
+                esz = _ESZ[x.dt]
+                self._emit('copy', 'concat_copy', 'fss_copy_channels',
+                           (x.ptr, x.ld, out.buf.data_ptr() + off * esz, ctot, n * h * w, c,
+                            _CODE[x.dt], self.sh), nbytes=2 * n * h * w * c * esz)
+            off += c
+
+    # ---- argmax / lut / crop
+    def _l_argmax(self, ln):
+        src = ln.inputs[0]
+        d = self.lazy.get(src)
+        full_ptr = None
+        n, ho, wo, _ = ln.shape
+        if d and d[0] == 'resize' and d[2] and self._val(d[1]).dt == 'f32':
+            x = self._val(d[1])
+            if src.is_output or len(src.consumers) > 1:
+                # the zoomed logits are wanted too: the fused kernel stores them
+                self.lazy.pop(src)
+                full = Val(self._alloc(src.shape, 'f32'), src.shape, 'f32')
+                self.vals[src] = full
+                full_ptr = full.ptr
+        else:
+            x = self._val(src)
+        if x.dt != 'f32' or not x.dense:
+            raise NotImplementedError('argmax expects dense float32 logits')
+        _, h, w, c = x.shape
+        labels = Val(torch.empty((n, ho, wo, 1), dtype=torch.uint8, device=self.device),
+                     (n, ho, wo, 1), 'u8')
+        self.vals[ln] = labels
+        self._emit('argmax', 'upsample_argmax', 'fss_upsample_argmax',
+                   (x.ptr, labels.ptr, full_ptr, n, h, w, c, ho, wo, self.sh),
+                   nbytes=n * h * w * c * 4 + n * ho * wo + (n * ho * wo * c * 4 if full_ptr else 0))
+
+    def _l_lut(self, ln):
+        labels = self._val(ln.inputs[0])
+        if labels.dt != 'u8':
+            raise NotImplementedError('lut expects a label map')
+        n, h, w, _ = labels.shape
+        table = np.asarray(ln.attrs['table'], np.float32)
+        tdev = self._dev_f32(table)
+        ho, wo, result = h, w, ln
+        crop = self._only_consumer(ln, 'crop')
+        if crop is not None:
+            _, ho, wo, _ = crop.shape
+            result = crop
+            self.fused.add(crop)
+        ch = table.shape[1]
+        out = Val(self._alloc((n, ho, wo, ch), 'f32'), (n, ho, wo, ch), 'f32')
+        self.vals[result] = out
+        self._emit('lut', 'label_lut', 'fss_label_lut',
+                   (labels.ptr, out.ptr, tdev.data_ptr(), n, h, w, ho, wo, ch, table.shape[0],
+                    self.sh), nbytes=n * ho * wo * (1 + 4 * ch))
+
+    def _l_crop(self, ln):
+        # not fused into a lut: a top-left view, resolved when the value is fetched
+        src = self._val(ln.inputs[0])
+        self.vals[ln] = Val(src.buf, ln.shape, src.dt, phys_c=src.phys_c, ld=src.ld, coff=src.coff)
+
+    # -------------------------------------------------------------- execution
+    def run_eager(self):
+        for s in self.steps:
+            check(s.fn(*s.args), s.kind + ':' + s.name)
+
+    def _capture(self):
+        _lib.call('fss_capture_begin', self.sh)
+        ex = ctypes.c_void_p()
+        try:
+            self.run_eager()
+        finally:
+            _lib.call('fss_capture_end', self.sh, ctypes.byref(ex))
+        self.graph_exec = ex
+
+    def launch(self):
+        """Enqueues one forward pass on the plan's stream (asynchronous)."""
+        if self.graph_exec is not None:
+            _lib.call('fss_graph_launch', self.graph_exec, self.sh)
+        else:
+            self.run_eager()
+
+    def sync(self):
+        self.stream.synchronize()
+
+    def set_input(self, images_u8):
+        """Copies a uint8 [n,h,w,3] (or [h,w,3]) host array into the input buffer."""
+        a = np.ascontiguousarray(images_u8, dtype=np.uint8)
+        if a.ndim == 3:
+            a = a[None]
+        if tuple(a.shape) != tuple(self.input_val.shape):
+            raise ValueError('input shape %s does not match the placeholder %s'
+                             % (a.shape, self.input_val.shape))
+        with torch.cuda.stream(self.stream):
+            self.input_val.buf.copy_(torch.from_numpy(a))
+
+    def value(self, tensor):
+        """Device value (`Val`) of a graph tensor given in `outputs`."""
+        return self.vals[self.out_nodes[tensor.node.index]]
+
+    def fetch(self, tensor):
+        """Device -> host copy of an output tensor as a numpy array (logical shape)."""
+        v = self.value(tensor)
+        self.sync()
+        n, h, w, c = v.shape
+        t = v.buf.reshape(v.buf.shape[0], v.buf.shape[1], v.buf.shape[2], -1)
+        with torch.cuda.stream(self.stream):
+            t = t[:, :h, :w, v.coff:v.coff + c]
+            if t.dtype == torch.bfloat16:
+                t = t.float()
+            out = t.cpu()
+        return out.numpy()
+
+    def run(self, images_u8, fetch=None):
+        """set_input + launch + fetch (all outputs by default)."""
+        self.set_input(images_u8)
+        self.launch()
+        return [self.fetch(t) for t in (fetch if fetch is not None else self.outputs)]
+
+    def __del__(self):
+        try:
+            if self.graph_exec is not None:
+                lib.fss_graph_destroy(self.graph_exec)
+        except Exception:
+            pass
+
+    # -------------------------------------------------------------- profiling
+    def profile(self, repeats=3):
+        """Times every launch with HIP events recorded on the plan's stream
+        (eager mode).  Returns a list of dicts (kind, name, ms, flops, bytes),
+        ms = the best of `repeats` runs."""
+        n = len(self.steps)
+        evs = []
+        for _ in range(n + 1):
+            e = ctypes.c_void_p()
+            _lib.call('fss_event_create', ctypes.byref(e))
+            evs.append(e)
+        best = [float('inf')] * n
+        for _ in range(repeats):
+            _lib.call('fss_event_record', evs[0], self.sh)
+            for k, s in enumerate(self.steps):
+                check(s.fn(*s.args), s.name)
+                _lib.call('fss_event_record', evs[k + 1], self.sh)
+            _lib.call('fss_event_sync', evs[n])
+            for k in range(n):
+                ms = ctypes.c_float()
+                _lib.call('fss_event_elapsed_ms', evs[k], evs[k + 1], ctypes.byref(ms))
+                best[k] = min(best[k], ms.value)
+        for e in evs:
+            _lib.call('fss_event_destroy', e)
+        return [dict(kind=s.kind, name=s.name, ms=best[k], flops=s.flops, bytes=s.bytes)
+                for k, s in enumerate(self.steps)]

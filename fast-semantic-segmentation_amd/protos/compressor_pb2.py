@@ -1,0 +1,5 @@
+"""Message classes of the reference's protos/compressor.proto, built at import time
+(see protos/_schema.py); stands in for the protoc-generated module."""
+from protos import _schema
+
+_schema.export(globals(), ['CommpressionConfig', 'CompressionStrategy', 'FilterPruner', 'SingleNodePruningSpec', 'NodeName'])

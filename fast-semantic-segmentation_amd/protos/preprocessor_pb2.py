@@ -1,0 +1,5 @@
+"""Message classes of the reference's protos/preprocessor.proto, built at import time
+(see protos/_schema.py); stands in for the protoc-generated module."""
+from protos import _schema
+
+_schema.export(globals(), ['PreprocessingStep', 'SetFixedImageSize', 'AspectRatioImageResize', 'RandomImageScale', 'RandomCropImage', 'RandomHorizontalFlip'])

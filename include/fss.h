@@ -1,0 +1,194 @@
+/*
+ * libfss_gfx950 -- C ABI of the MI355X (gfx950) segmentation forward-pass kernels.
+ *
+ * The reference project (oandrienko/fast-semantic-segmentation) has no FFI of
+ * its own: every arithmetic op on its inference / evaluation path is a call
+ * into TensorFlow 1.8.  Each entry point below replaces one such op (or a
+ * fixed chain of them); the comment names the reference call site(s), as
+ * file:line relative to the reference checkout.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure;
+ *     fss_last_error() returns a thread-local message for the last failure.
+ *   - all tensor pointers are DEVICE pointers owned by the caller; activations
+ *     are NHWC, dense unless a pixel stride ("ld", in elements) is given.
+ *   - `stream` is a hipStream_t (NULL = the null stream); launches are
+ *     asynchronous on it.  No entry point in the "kernels" section allocates,
+ *     frees or synchronises, so a sequence of them can be stream-captured.
+ *   - dtype codes: FSS_F32 = float, FSS_BF16 = bfloat16 (uint16 storage).
+ */
+#ifndef FSS_H_
+#define FSS_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSS_F32 0
+#define FSS_BF16 1
+
+#define FSS_ACT_NONE 0
+#define FSS_ACT_RELU 1
+#define FSS_ACT_RELU6 2
+
+/* ------------------------------------------------------------------ runtime */
+const char* fss_last_error(void);
+int fss_version(void);
+int fss_device_count(int* count);
+int fss_set_device(int device);
+int fss_device_name(char* buf, int buflen);
+
+int fss_malloc(void** ptr, size_t bytes);
+int fss_free(void* ptr);
+int fss_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int fss_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int fss_memset(void* dst, int value, size_t bytes, void* stream);
+
+int fss_stream_create(void** stream);
+int fss_stream_destroy(void* stream);
+int fss_stream_sync(void* stream);
+int fss_device_sync(void);
+
+int fss_event_create(void** event);
+int fss_event_destroy(void* event);
+int fss_event_record(void* event, void* stream);
+int fss_event_sync(void* event);
+int fss_event_elapsed_ms(void* start, void* stop, float* ms);
+
+/* Stream capture of a whole forward pass into a hipGraph.  Replaces the role
+ * of the TF session plan that inference.py:97-98 / libs/evaluator.py:188-199
+ * re-run once per image. */
+int fss_capture_begin(void* stream);
+int fss_capture_end(void* stream, void** graph_exec);
+int fss_graph_launch(void* graph_exec, void* stream);
+int fss_graph_destroy(void* graph_exec);
+
+/* ------------------------------------------------------------------ kernels */
+
+/* Convolution descriptor.  Weights are pre-packed by the caller as
+ * Wp[cout_pad][k_pad] in the INPUT dtype, k = (r*kw + s)*cin + c, with the
+ * batch-norm scale folded in and zero padding; fss_conv_pack_dims gives
+ * k_pad / cout_pad.  cin must be a multiple of 16/sizeof(in dtype). */
+typedef struct fss_conv_desc {
+  int32_t n, h, w, cin;      /* input  [n,h,w,cin]                         */
+  int32_t cout, kh, kw;      /* filter [kh,kw,cin,cout]                    */
+  int32_t stride, dilation;
+  int32_t pad_top, pad_left; /* zero padding before the first row / column */
+  int32_t ho, wo;            /* output spatial size                        */
+  int32_t act;               /* FSS_ACT_*                                  */
+  int32_t in_dtype;          /* FSS_F32 | FSS_BF16 (x, weights, residual)  */
+  int32_t out_dtype;         /* FSS_F32 | FSS_BF16                         */
+  int32_t y_ld;              /* output pixel stride in elements (>= cout)  */
+  int32_t res_ld;            /* residual pixel stride in elements          */
+  int32_t k_pad, cout_pad;   /* packed weight dims                         */
+} fss_conv_desc;
+
+int fss_conv_pack_dims(int cin, int kh, int kw, int cout, int dtype,
+                       int* k_pad, int* cout_pad);
+
+/* y = act(conv(x, W) + bias [+ residual]).
+ * Replaces slim.conv2d + slim.batch_norm(inference) + activation
+ * (libs/compressible_ops.py:9-24, third_party/dilated_resnet_v1.py:90-102,
+ * third_party/resnet_utils.py:111-122, architectures/icnet_architecture.py:208-247,
+ * architectures/pspnet_architecture.py:135,144) and, with `residual`, the
+ * shortcut add + relu of third_party/dilated_resnet_v1.py:109, the add + relu of
+ * architectures/icnet_architecture.py:251-252 and third_party/conv_blocks.py:313.
+ * `residual` has the output's shape and the input dtype; NULL = none. */
+int fss_conv2d_nhwc(const fss_conv_desc* desc, const void* x, const void* w_packed,
+                    const float* bias, const void* residual, void* y, void* stream);
+
+/* Depthwise 3x3-style convolution + bias + activation.
+ * Replaces slim.separable_conv2d(num_outputs=None) + batch_norm + relu6
+ * (third_party/conv_blocks.py:240-249,280).  w: float [kh*kw][c] (BN folded). */
+int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y,
+                      int n, int h, int wd, int c, int kh, int kw, int stride,
+                      int dilation, int pad_top, int pad_left, int ho, int wo,
+                      int act, int dtype, void* stream);
+
+/* Max pooling; padded taps are ignored.
+ * Replaces slim.max_pool2d(net, [3,3], stride=2) under SAME
+ * (third_party/dilated_resnet_v1.py:175). */
+int fss_maxpool_nhwc(const void* x, void* y, int n, int h, int wd, int c, int k,
+                     int stride, int pad_top, int pad_left, int ho, int wo,
+                     int dtype, void* stream);
+
+/* y[n,i,j,:] = x[n,i*stride,j*stride,:].
+ * Replaces resnet_utils.subsample = max_pool2d([1,1], stride)
+ * (third_party/resnet_utils.py:59-74). */
+int fss_subsample_nhwc(const void* x, void* y, int n, int h, int wd, int c,
+                       int stride, int ho, int wo, int dtype, void* stream);
+
+/* VALID average pooling with kernel == stride == (kh,kw).
+ * Replaces slim.avg_pool2d(x, (kh,kw), stride=(kh,kw))
+ * (architectures/icnet_architecture.py:197-200,
+ * architectures/pspnet_architecture.py:130-133).  y: [n,bh,bw,c]. */
+int fss_avgpool_bins_nhwc(const void* x, void* y, int n, int h, int wd, int c,
+                          int kh, int kw, int bh, int bw, int dtype, void* stream);
+
+/* tf.image.resize_bilinear (TF 1.x legacy sampling), optional align_corners.
+ * Replaces architectures/icnet_architecture.py:249,264-266,
+ * architectures/pspnet_architecture.py:136-139,158-160,
+ * third_party/dilated_resnet_v1.py:45-47, third_party/mobilenet_v2.py:49-51,
+ * libs/evaluator.py:68-71.  y_ld = output pixel stride in elements. */
+int fss_resize_bilinear_nhwc(const void* x, void* y, int n, int h, int wd, int c,
+                             int ho, int wo, int y_ld, int align_corners,
+                             int dtype, void* stream);
+
+/* y = x + sum_i resize_bilinear_align_corners(p_i) for up to 8 pooled maps,
+ * added in index order.  Replaces the avg_pool -> resize -> tf.add loop of
+ * architectures/icnet_architecture.py:194-205.  p[i]: [n,bh[i],bw[i],c]. */
+int fss_pyramid_add_nhwc(const void* x, const void* const* p, const int* bh,
+                         const int* bw, int levels, void* y, int n, int h, int wd,
+                         int c, int dtype, void* stream);
+
+/* y = act(a + b), elementwise. (third_party/dilated_resnet_v1.py:109,
+ * architectures/icnet_architecture.py:251-252 when not fused into a conv.) */
+int fss_add_act(const void* a, const void* b, void* y, size_t count, int act,
+                int dtype, void* stream);
+
+/* Copies a [pixels, c] tensor into / out of a wider one (channel concat).
+ * Replaces tf.concat(axis=-1) (architectures/pspnet_architecture.py:143). */
+int fss_copy_channels(const void* x, int x_ld, void* y, int y_ld, size_t pixels,
+                      int c, int dtype, void* stream);
+
+/* uint8 image -> zero-padded, mean-subtracted, scaled float tensor:
+ * y[n,i,j,ch] = ((i<h && j<w ? x[n,i,j,ch] : 0) - mean[ch]) * scale[ch] for
+ * ch < 3, and 0 for 3 <= ch < c_out.  Replaces tf.image.pad_to_bounding_box +
+ * tf.to_float + extractor.preprocess (libs/exporter.py:37-38,52-53,
+ * extractors/pspnet_icnet_resnet_v1.py:43-45,
+ * extractors/pspnet_icnet_mobilenet_v2.py:44-46). */
+int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho,
+                      int wo, int c_out, const float* mean3, const float* scale3,
+                      int dtype, void* stream);
+
+/* Bilinear (align_corners) upsample of float logits [n,h,w,c] to [n,ho,wo]
+ * fused with argmax over channels (lowest index wins ties); labels are uint8.
+ * If `logits_out` is non-NULL the upsampled logits [n,ho,wo,c] are stored too.
+ * Replaces _dynamic_interpolation(z_factor) + tf.argmax(.., 3)
+ * (architectures/icnet_architecture.py:142-144, libs/exporter.py:41,
+ * libs/evaluator.py:65-72,85). */
+int fss_upsample_argmax(const float* logits, uint8_t* labels, float* logits_out,
+                        int n, int h, int wd, int c, int ho, int wo, void* stream);
+
+/* y[n,i,j,:] = table[labels[n,i,j]] for i<ho, j<wo (top-left crop).
+ * Replaces one_hot @ color_table + crop_to_bounding_box
+ * (libs/exporter.py:14-29,71-73).  table: float [num_classes][channels]. */
+int fss_label_lut(const uint8_t* labels, float* y, const float* table, int n,
+                  int h, int wd, int ho, int wo, int channels, int num_classes,
+                  void* stream);
+
+/* cm[label*num_classes + pred] += 1 for every pixel whose label != ignore_label;
+ * labels == ignore_label are dropped (weight 0).  cm is int64 and is
+ * accumulated into (not cleared).  Replaces the ignore mask +
+ * tf.contrib.metrics.streaming_mean_iou update op (libs/evaluator.py:143-154). */
+int fss_confusion_accumulate(const uint8_t* pred, const uint8_t* labels,
+                             size_t count, int num_classes, int ignore_label,
+                             int64_t* cm, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSS_H_ */

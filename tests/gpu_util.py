@@ -1,0 +1,70 @@
+"""Helpers for the GPU parity tests: thin numpy -> C-ABI -> numpy wrappers.
+Every call goes through libfss_gfx950.so via ctypes (fss._lib)."""
+import ctypes
+
+import numpy as np
+import torch
+
+from fss import _lib
+from fss.plan import f32_to_bf16_bits
+
+DT = {'f32': (_lib.F32, torch.float32, 4), 'bf16': (_lib.BF16, torch.bfloat16, 8)}
+
+
+def bf16_round(a):
+    """float32 -> nearest bfloat16 value, as float32."""
+    bits = f32_to_bf16_bits(np.asarray(a, np.float32)).astype(np.uint32) << 16
+    return bits.view(np.float32).reshape(np.shape(a))
+
+
+def to_dev(a, dt):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    return t.to(DT[dt][1]).contiguous()
+
+
+def to_host(t):
+    torch.cuda.synchronize()
+    return t.float().cpu().numpy()
+
+
+def pack_conv_weights(w, dt, cin_phys=None):
+    kh, kw, cin, cout = w.shape
+    pc = cin_phys or cin
+    if pc != cin:
+        w = np.pad(w, ((0, 0), (0, 0), (0, pc - cin), (0, 0)))
+    k_pad, cout_pad = _lib.conv_pack_dims(pc, kh, kw, cout, DT[dt][0])
+    wp = np.zeros((cout_pad, k_pad), np.float32)
+    wp[:cout, :kh * kw * pc] = w.transpose(3, 0, 1, 2).reshape(cout, -1)
+    if dt == 'bf16':
+        dev = torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
+    else:
+        dev = torch.from_numpy(wp).cuda()
+    return dev, k_pad, cout_pad
+
+
+def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw=None,
+           act=None, dt='f32', out_dt=None, y_ld=None):
+    """x: [n,h,w,cin] float32 host array; returns float32 host array [n,ho,wo,cout]."""
+    out_dt = out_dt or dt
+    n, h, wd, cin = x.shape
+    kh, kw, _, cout = w.shape
+    ho, wo = out_hw
+    xd = to_dev(x, dt)
+    wdev, k_pad, cout_pad = pack_conv_weights(w, dt)
+    bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda() if bias is not None else None
+    rd = to_dev(residual, dt) if residual is not None else None
+    ld = y_ld or cout
+    y = torch.full((n, ho, wo, ld), -77.0, dtype=DT[out_dt][1], device='cuda')
+    d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride,
+                      dilation=rate, pad_top=pads[0], pad_left=pads[1], ho=ho, wo=wo,
+                      act=_lib.ACT_CODES[act], in_dtype=DT[dt][0], out_dtype=DT[out_dt][0],
+                      y_ld=ld, res_ld=cout, k_pad=k_pad, cout_pad=cout_pad)
+    torch.cuda.synchronize()
+    _lib.call('fss_conv2d_nhwc', ctypes.byref(d), xd.data_ptr(), wdev.data_ptr(),
+              bd.data_ptr() if bd is not None else None,
+              rd.data_ptr() if rd is not None else None, y.data_ptr(), None)
+    _lib.call('fss_device_sync')
+    out = to_host(y)
+    if ld != cout:
+        assert np.all(out[..., cout:] == -77.0), 'kernel wrote outside its channel slice'
+    return out[..., :cout]

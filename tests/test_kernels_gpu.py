@@ -1,0 +1,330 @@
+"""Parity of every C-ABI kernel against the numpy oracle (seeded inputs).
+
+Float tolerances (stated per test): float32 kernels must match the float64
+oracle to 2e-4 of the output scale (the reference's float32 runtime itself is
+only that exact); bfloat16 kernels are fed bf16-representable inputs, so with
+float32 output they must match as tightly, and with bf16 output to 1/128
+(one bf16 rounding).  Integer outputs (labels, confusion matrix) are bit-exact.
+"""
+import ctypes
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ops as O           # noqa: E402
+from oracle import metrics as OM      # noqa: E402
+
+
+def _lib():
+    from fss import _lib as L
+    return L
+
+
+def _gu():
+    import gpu_util
+    return gpu_util
+
+
+def _close(got, ref, rtol, what=''):
+    scale = max(float(np.abs(ref).max()), 1e-6)
+    err = float(np.abs(got - ref).max()) / scale
+    assert err <= rtol, '%s: max err %.3g of scale (limit %.3g)' % (what, err, rtol)
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, rate, mode
+    (1, 17, 23, 8, 19, 1, 1, 1, 'SAME'),       # classifier-like, N tile 32
+    (2, 13, 17, 16, 64, 3, 1, 1, 'SAME'),      # N tile 64
+    (1, 33, 65, 32, 96, 3, 1, 4, 'SAME'),      # dilation 4, 64x64 tiles
+    (1, 33, 65, 64, 128, 3, 1, 16, 'SAME'),    # dilation 16 on a 33-row map
+    (1, 40, 52, 8, 40, 3, 2, 1, 'SAME'),       # strided SAME on even sizes (asymmetric pad)
+    (1, 41, 53, 8, 24, 3, 2, 1, 'FIXED'),      # conv2d_same explicit padding, stride 2
+    (1, 37, 45, 8, 32, 7, 2, 1, 'FIXED'),      # 7x7/2 root conv shape
+    (3, 96, 100, 64, 256, 1, 1, 1, 'SAME'),    # M = 28800: 128x128 tiles
+    (1, 65, 129, 40, 72, 3, 1, 2, 'SAME'),     # cin, cout not multiples of 32
+    (1, 9, 9, 24, 144, 1, 1, 1, 'SAME'),       # K smaller than one K tile
+]
+
+
+def _conv_ref(x, w, stride, rate, mode, dtype=np.float64):
+    if mode == 'SAME':
+        return O.conv2d(x, w, stride, rate, 'SAME', dtype)
+    return O.conv2d_same(x, w, stride, rate, dtype)
+
+
+def _conv_pads(h, wd, k, stride, rate, mode):
+    if mode == 'SAME':
+        ho, pt, _ = O.same_padding(h, k, stride, rate)
+        wo, pl, _ = O.same_padding(wd, k, stride, rate)
+        return (pt, pl), (ho, wo)
+    pb, pe = O.fixed_padding(k, rate)
+    keff = k + (k - 1) * (rate - 1)
+    return (pb, pb), ((h + pb + pe - keff) // stride + 1, (wd + pb + pe - keff) // stride + 1)
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_conv2d(case, dt):
+    gu = _gu()
+    n, h, wd, cin, cout, k, stride, rate, mode = case
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    x = rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32)
+    w = rng.normal(0, 1 / np.sqrt(k * k * cin), (k, k, cin, cout)).astype(np.float32)
+    bias = rng.normal(0, 0.5, cout).astype(np.float32)
+    if dt == 'bf16':
+        x, w = gu.bf16_round(x), gu.bf16_round(w)
+    pads, out_hw = _conv_pads(h, wd, k, stride, rate, mode)
+    ref = _conv_ref(x, w, stride, rate, mode) + bias
+    assert ref.shape[1:3] == out_hw
+    got = gu.conv2d(x, w, bias, None, stride, rate, pads, out_hw, None, dt,
+                    out_dt='f32')
+    _close(got, ref, 2e-4, 'conv %s %s' % (dt, case,))
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('act', [None, 'relu', 'relu6'])
+def test_conv2d_epilogue(dt, act):
+    """bias + residual + activation, output written into a wider pixel stride."""
+    gu = _gu()
+    rng = np.random.default_rng(7)
+    n, h, wd, cin, cout = 2, 21, 19, 32, 48
+    x = rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32)
+    w = rng.normal(0, 0.2, (3, 3, cin, cout)).astype(np.float32)
+    bias = rng.normal(0, 1, cout).astype(np.float32)
+    res = rng.normal(0, 2, (n, h, wd, cout)).astype(np.float32)
+    if dt == 'bf16':
+        x, w, res = gu.bf16_round(x), gu.bf16_round(w), gu.bf16_round(res)
+    ref = O.conv2d(x, w, 1, 1, 'SAME', np.float64) + bias + res
+    ref = {'relu': O.relu, 'relu6': O.relu6, None: lambda v: v}[act](ref)
+    got = gu.conv2d(x, w, bias, res, 1, 1, (1, 1), (h, wd), act, dt, y_ld=cout + 16)
+    _close(got, ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'conv epilogue %s %s' % (dt, act))
+
+
+def test_conv2d_rejects_bad_arguments():
+    L = _lib()
+    d = L.ConvDesc(n=1, h=8, w=8, cin=3, cout=8, kh=3, kw=3, stride=1, dilation=1, pad_top=1,
+                   pad_left=1, ho=8, wo=8, act=0, in_dtype=L.F32, out_dtype=L.F32, y_ld=8,
+                   res_ld=0, k_pad=64, cout_pad=128)
+    buf = torch.zeros(4096, device='cuda')
+    rc = L.lib.fss_conv2d_nhwc(ctypes.byref(d), buf.data_ptr(), buf.data_ptr(), None, None,
+                               buf.data_ptr(), None)
+    assert rc != 0 and b'cin' in L.lib.fss_last_error()
+
+
+def _call(name, *args):
+    _lib().call(name, *args)
+    _lib().call('fss_device_sync')
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_depthwise(dt):
+    gu, L = _gu(), _lib()
+    rng = np.random.default_rng(3)
+    for (n, h, wd, c, stride, rate) in [(1, 33, 65, 96, 1, 4), (2, 20, 26, 24, 2, 1),
+                                        (1, 17, 33, 144, 1, 2), (1, 9, 11, 32, 2, 1)]:
+        x = rng.normal(0, 1, (n, h, wd, c)).astype(np.float32)
+        w = rng.normal(0, 0.4, (3, 3, c, 1)).astype(np.float32)
+        bias = rng.normal(0, 0.5, c).astype(np.float32)
+        if dt == 'bf16':
+            x = gu.bf16_round(x)
+        ref = O.relu6(O.depthwise_conv2d(x, w, stride, rate, np.float64) + bias)
+        ho, pt, _ = O.same_padding(h, 3, stride, rate)
+        wo, pl, _ = O.same_padding(wd, 3, stride, rate)
+        xd = gu.to_dev(x, dt)
+        wdv = torch.from_numpy(w[:, :, :, 0].reshape(9, c).copy()).cuda()
+        bd = torch.from_numpy(bias).cuda()
+        y = torch.empty((n, ho, wo, c), dtype=gu.DT[dt][1], device='cuda')
+        _call('fss_dwconv2d_nhwc', xd.data_ptr(), wdv.data_ptr(), bd.data_ptr(), y.data_ptr(),
+              n, h, wd, c, 3, 3, stride, rate, pt, pl, ho, wo, L.ACT_RELU6, gu.DT[dt][0], None)
+        _close(gu.to_host(y), ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'depthwise')
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_pools_and_subsample(dt):
+    gu = _gu()
+    rng = np.random.default_rng(4)
+    code, tdt, epc = gu.DT[dt]
+    for (n, h, wd, c) in [(1, 37, 41, 64), (2, 40, 52, 16)]:
+        x = rng.normal(0, 1, (n, h, wd, c)).astype(np.float32)
+        if dt == 'bf16':
+            x = gu.bf16_round(x)
+        xd = gu.to_dev(x, dt)
+        # max pool 3x3/2 SAME: exact (selection only)
+        ref = O.max_pool_same(x, 3, 2)
+        ho, pt, _ = O.same_padding(h, 3, 2)
+        wo, pl, _ = O.same_padding(wd, 3, 2)
+        y = torch.empty((n, ho, wo, c), dtype=tdt, device='cuda')
+        _call('fss_maxpool_nhwc', xd.data_ptr(), y.data_ptr(), n, h, wd, c, 3, 2, pt, pl, ho, wo,
+              code, None)
+        assert np.array_equal(gu.to_host(y), ref)
+        # subsample: exact
+        ref = O.subsample(x, 2)
+        y = torch.empty(ref.shape, dtype=tdt, device='cuda')
+        _call('fss_subsample_nhwc', xd.data_ptr(), y.data_ptr(), n, h, wd, c, 2, ref.shape[1],
+              ref.shape[2], code, None)
+        assert np.array_equal(gu.to_host(y), ref)
+        # avg pool bins, including dropped remainder rows / columns
+        for f in (1, 2, 3, 4, 6):
+            kh, kw = int(h / f), int(wd / f)
+            ref = O.avg_pool_valid(x.astype(np.float64), kh, kw)
+            y = torch.empty(ref.shape, dtype=tdt, device='cuda')
+            _call('fss_avgpool_bins_nhwc', xd.data_ptr(), y.data_ptr(), n, h, wd, c, kh, kw,
+                  ref.shape[1], ref.shape[2], code, None)
+            _close(gu.to_host(y), ref, 1e-5 if dt == 'f32' else 1.0 / 128, 'avgpool f=%d' % f)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_resize_bilinear(dt):
+    gu = _gu()
+    rng = np.random.default_rng(5)
+    code, tdt, epc = gu.DT[dt]
+    cases = [((1, 33, 65, 16), (65, 129), True), ((2, 17, 21, 8), (9, 11), True),
+             ((1, 3, 3, 32), (33, 65), True), ((1, 1, 1, 8), (9, 17), True),
+             ((1, 6, 6, 8), (90, 90), True), ((1, 10, 12, 8), (23, 31), False),
+             ((1, 1025 // 8, 2049 // 8, 8), (512 // 8 + 1, 129), True)]
+    for shape, (ho, wo), align in cases:
+        x = rng.normal(0, 1, shape).astype(np.float32)
+        if dt == 'bf16':
+            x = gu.bf16_round(x)
+        ref = O.resize_bilinear(x, ho, wo, align)
+        xd = gu.to_dev(x, dt)
+        n, h, wd, c = shape
+        y = torch.empty((n, ho, wo, c), dtype=tdt, device='cuda')
+        _call('fss_resize_bilinear_nhwc', xd.data_ptr(), y.data_ptr(), n, h, wd, c, ho, wo, c,
+              1 if align else 0, code, None)
+        # same float32 formula as the oracle: exact for f32 up to fma contraction
+        _close(gu.to_host(y), ref, 2e-6 if dt == 'f32' else 1.0 / 128, 'resize %s' % (shape,))
+    # float32 logits with 19 channels (scalar path) into a strided destination
+    x = rng.normal(0, 1, (1, 9, 11, 19)).astype(np.float32)
+    ref = O.resize_bilinear(x, 17, 21, True)
+    xd = gu.to_dev(x, 'f32')
+    y = torch.zeros((1, 17, 21, 24), dtype=torch.float32, device='cuda')
+    _call('fss_resize_bilinear_nhwc', xd.data_ptr(), y.data_ptr(), 1, 9, 11, 19, 17, 21, 24, 1,
+          gu.DT['f32'][0], None)
+    got = gu.to_host(y)
+    _close(got[..., :19], ref, 2e-6, 'resize c=19')
+    assert np.all(got[..., 19:] == 0)
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_pyramid_add(dt):
+    gu = _gu()
+    rng = np.random.default_rng(6)
+    code, tdt, epc = gu.DT[dt]
+    n, h, wd, c = 2, 33, 65, 64
+    x = rng.normal(0, 1, (n, h, wd, c)).astype(np.float32)
+    if dt == 'bf16':
+        x = gu.bf16_round(x)
+    pooled = []
+    ref = x.astype(np.float32)
+    for f in (1, 2, 3, 4):
+        p = O.avg_pool_valid(x, int(h / f), int(wd / f)).astype(np.float32)
+        if dt == 'bf16':
+            p = gu.bf16_round(p)
+        pooled.append(p)
+        ref = ref + O.resize_bilinear(p, h, wd, True)
+    xd = gu.to_dev(x, dt)
+    pd = [gu.to_dev(p, dt) for p in pooled]
+    y = torch.empty((n, h, wd, c), dtype=tdt, device='cuda')
+    ptrs = (ctypes.c_void_p * 4)(*[p.data_ptr() for p in pd])
+    bh = (ctypes.c_int * 4)(*[p.shape[1] for p in pooled])
+    bw = (ctypes.c_int * 4)(*[p.shape[2] for p in pooled])
+    _call('fss_pyramid_add_nhwc', xd.data_ptr(), ptrs, bh, bw, 4, y.data_ptr(), n, h, wd, c, code,
+          None)
+    _close(gu.to_host(y), ref, 2e-6 if dt == 'f32' else 1.0 / 128, 'pyramid')
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_add_copy_preprocess(dt):
+    gu, L = _gu(), _lib()
+    rng = np.random.default_rng(8)
+    code, tdt, epc = gu.DT[dt]
+    a = rng.normal(0, 3, (2, 5, 7, 16)).astype(np.float32)
+    b = rng.normal(0, 3, (2, 5, 7, 16)).astype(np.float32)
+    if dt == 'bf16':
+        a, b = gu.bf16_round(a), gu.bf16_round(b)
+    ad, bd = gu.to_dev(a, dt), gu.to_dev(b, dt)
+    y = torch.empty_like(ad)
+    _call('fss_add_act', ad.data_ptr(), bd.data_ptr(), y.data_ptr(), a.size, L.ACT_RELU, code, None)
+    _close(gu.to_host(y), O.relu(a + b), 1e-6 if dt == 'f32' else 1.0 / 128, 'add')
+    # channel copy into a concat slice
+    big = torch.zeros((2, 5, 7, 48), dtype=tdt, device='cuda')
+    esz = big.element_size()
+    _call('fss_copy_channels', ad.data_ptr(), 16, big.data_ptr() + 16 * esz, 48, 2 * 5 * 7, 16, code,
+          None)
+    got = gu.to_host(big)
+    assert np.array_equal(got[..., 16:32], a) and np.all(got[..., :16] == 0) and np.all(got[..., 32:] == 0)
+    # preprocess: zero pad BEFORE mean subtraction
+    img = rng.integers(0, 256, (2, 10, 12, 3)).astype(np.uint8)
+    mean = np.array([123.68, 116.779, 103.939], np.float32)
+    scale = np.array([1.0, 1.0, 1.0], np.float32)
+    ref = O.pad_to_bounding_box(img.astype(np.float32), 11, 13) - mean
+    xd = torch.from_numpy(img).cuda()
+    y = torch.empty((2, 11, 13, epc), dtype=tdt, device='cuda')
+    _call('fss_preprocess_u8', xd.data_ptr(), y.data_ptr(), 2, 10, 12, 11, 13, epc,
+          mean.ctypes.data_as(L.c_float_p), scale.ctypes.data_as(L.c_float_p), code, None)
+    got = gu.to_host(y)
+    _close(got[..., :3], ref, 1e-6 if dt == 'f32' else 1.0 / 128, 'preprocess')
+    assert np.all(got[..., 3:] == 0)
+
+
+def test_upsample_argmax_lut_confusion():
+    gu, L = _gu(), _lib()
+    rng = np.random.default_rng(9)
+    n, h, wd, c = 2, 17, 33, 19
+    x = rng.normal(0, 1, (n, h, wd, c)).astype(np.float32)
+    x[0, 3, 4, :] = 1.0             # exact ties: lowest index must win
+    x[1, :, :, 5] = x[1, :, :, 2]   # tie between classes 2 and 5 everywhere
+    ho, wo = 65, 129
+    up = O.resize_bilinear(x, ho, wo, True)
+    ref = O.argmax_channels(up)
+    xd = torch.from_numpy(x).cuda()
+    lab = torch.empty((n, ho, wo), dtype=torch.uint8, device='cuda')
+    full = torch.empty((n, ho, wo, c), dtype=torch.float32, device='cuda')
+    _call('fss_upsample_argmax', xd.data_ptr(), lab.data_ptr(), full.data_ptr(), n, h, wd, c, ho, wo,
+          None)
+    got_full = full.cpu().numpy()
+    _close(got_full, up, 2e-6, 'upsampled logits')
+    got = lab.cpu().numpy().astype(np.int64)
+    # labels must be the exact argmax of the logits the kernel itself produced ...
+    assert np.array_equal(got, np.argmax(got_full, axis=3))
+    # ... and agree with the oracle wherever the oracle's top-2 margin exceeds rounding noise
+    s = np.sort(up, axis=3)
+    clear = (s[..., -1] - s[..., -2]) > 1e-5
+    assert np.array_equal(got[clear], ref[clear])
+    assert got[0, 0, 0] == ref[0, 0, 0]
+    # same-size call = plain argmax (tie rows included): bit-exact
+    lab2 = torch.empty((n, h, wd), dtype=torch.uint8, device='cuda')
+    _call('fss_upsample_argmax', xd.data_ptr(), lab2.data_ptr(), None, n, h, wd, c, h, wd, None)
+    assert np.array_equal(lab2.cpu().numpy().astype(np.int64), O.argmax_channels(x))
+    # colour LUT with crop
+    from libs.constants import CITYSCAPES_LABEL_COLORS, CITYSCAPES_LABEL_IDS
+    for table in (CITYSCAPES_LABEL_COLORS, CITYSCAPES_LABEL_IDS):
+        t = np.asarray(table, np.float32)
+        td = torch.from_numpy(t).cuda()
+        out = torch.empty((n, ho - 1, wo - 1, t.shape[1]), dtype=torch.float32, device='cuda')
+        _call('fss_label_lut', lab.data_ptr(), out.data_ptr(), td.data_ptr(), n, ho, wo, ho - 1,
+              wo - 1, t.shape[1], t.shape[0], None)
+        refc = O.map_to_colored_labels(got, table)[:, :ho - 1, :wo - 1]
+        assert np.array_equal(out.cpu().numpy(), refc)
+    # confusion matrix: bit-exact, accumulates across calls, ignore label dropped
+    labels = rng.integers(0, 19, (n, ho, wo)).astype(np.uint8)
+    labels[rng.random(labels.shape) < 0.05] = 255
+    labels[0, :8] = 3               # long uniform runs
+    ld = torch.from_numpy(labels).cuda()
+    cm = torch.zeros((19, 19), dtype=torch.int64, device='cuda')
+    for _ in range(2):
+        _call('fss_confusion_accumulate', lab.data_ptr(), ld.data_ptr(), labels.size, 19, 255,
+              cm.data_ptr(), None)
+    refcm = OM.confusion_matrix(got, labels, 19, 255)
+    assert np.array_equal(cm.cpu().numpy(), 2 * refcm)
+    # empty input is a no-op; all-ignore adds nothing
+    _call('fss_confusion_accumulate', lab.data_ptr(), ld.data_ptr(), 0, 19, 255, cm.data_ptr(), None)
+    allign = torch.full_like(ld, 255)
+    _call('fss_confusion_accumulate', lab.data_ptr(), allign.data_ptr(), labels.size, 19, 255,
+          cm.data_ptr(), None)
+    assert np.array_equal(cm.cpu().numpy(), 2 * refcm)

@@ -1,0 +1,141 @@
+"""End-to-end parity: the HIP forward pass vs the numpy oracle on the same
+synthetic weights and seeded inputs, at sizes the oracle finishes in seconds.
+
+Tolerances are the ones the task states: logits within 1e-3 (float32) / 2e-2
+(bfloat16) of the logit scale, argmax agreement >= 99.9 % in float32; label
+maps, colour maps, confusion matrix and mIoU bit-exact given identical labels.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets, ops as O, metrics as OM     # noqa: E402
+
+CFG = """
+model { %(arch)s { num_classes: 19 filter_scale: %(fs)s pooling_factors: %(pf)s
+  feature_extractor { type: '%(ext)s' }
+  hyperparams { batch_norm { train: true scale: true center: true decay: 0.9997 epsilon: 0.00001 }
+                regularizer { l2_regularizer { weight: 0.0001 } }
+                initializer { variance_scaling_initializer {} } }
+  loss { classification_loss { softmax {} } use_auxiliary_loss: true } } }
+eval_config: { num_examples: 4 eval_input_type { padded_eval_input { height: %(h)d width: %(w)d } } }
+"""
+
+
+def build(arch, ext, fs, pf, in_shape, pad_shape, color_map=None):
+    from google.protobuf import text_format
+    from protos import pipeline_pb2
+    from builders import model_builder
+    from fss import graph as G, synth
+    from libs import exporter
+    cfg = pipeline_pb2.PipelineConfig()
+    text_format.Merge(CFG % dict(arch=arch, ext=ext, fs=fs, pf=pf, h=pad_shape[0], w=pad_shape[1]), cfg)
+    g = G.reset_default_graph()
+    _, model = model_builder.build(cfg.model, is_training=False)
+    placeholder, inp = exporter._image_tensor_input_placeholder(in_shape, pad_shape)
+    pre = model.preprocess(G.to_float(inp))
+    logits = model.predict(pre)[model.main_class_predictions_key]
+    labels = G.argmax(logits, 3)
+    outs = [logits, labels]
+    if color_map is not None:
+        n_in = in_shape if len(in_shape) == 3 else in_shape[1:]
+        outs.append(G.crop_to_bounding_box(G.map_to_colored_labels(labels, color_map), 0, 0,
+                                           n_in[0], n_in[1]))
+    istd = 70.0 if ext == 'dilated_resnet50' else 0.55
+    weights = synth.make_weights(g.variables, seed=1234, input_std=istd)
+    return g, cfg, outs, weights
+
+
+def oracle_logits(arch, ext, fs, pf, img, pad_shape, weights):
+    x = O.pad_to_bounding_box(img.astype(np.float32), pad_shape[0], pad_shape[1])
+    x = nets.preprocess(x, ext)
+    P = nets.Params(weights)
+    fn = nets.icnet_predict if arch == 'icnet' else nets.pspnet_predict
+    return fn(P, x, filter_scale=1.0 / fs, pooling_factors=pf, extractor=ext)
+
+
+CASES = [
+    ('icnet', 'dilated_resnet50', 1.0, [1.0, 2.0, 3.0, 4.0], (2, 256, 512, 3), (257, 513)),
+    ('icnet', 'dilated_resnet50', 0.5, [1.0, 2.0, 3.0, 4.0], (1, 320, 448, 3), (321, 449)),
+    ('pspnet', 'dilated_resnet50', 1.0, [1.0, 2.0, 3.0, 6.0], (2, 193, 193, 3), (193, 193)),
+    ('icnet', 'dilated_mobilenet', 1.0, [1.0, 2.0, 3.0, 4.0], (1, 256, 512, 3), (257, 513)),
+    ('pspnet', 'dilated_mobilenet', 1.0, [1.0, 2.0, 3.0, 6.0], (1, 193, 193, 3), (193, 193)),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=lambda c: '%s-%s-%s' % (c[0], c[1], c[2]))
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_forward_parity(case, dtype):
+    from fss import plan
+    from libs.constants import CITYSCAPES_LABEL_COLORS
+    arch, ext, fs, pf, in_shape, pad_shape = case
+    g, cfg, outs, weights = build(arch, ext, fs, pf, in_shape, pad_shape, CITYSCAPES_LABEL_COLORS)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, in_shape).astype(np.uint8)
+    ref = oracle_logits(arch, ext, fs, pf, img, pad_shape, weights)
+    cg = plan.CompiledGraph(g, outs, weights, dtype=dtype)
+    logits, labels, colors = cg.run(img)
+    assert logits.shape == ref.shape
+    scale = float(np.abs(ref).max())
+    err = float(np.abs(logits - ref).max()) / scale
+    ref_lab = O.argmax_channels(ref)
+    agree = float((labels[..., 0] == ref_lab).mean())
+    print('%s %s: logit err %.3g of scale, argmax agreement %.5f' % (case[:3], dtype, err, agree))
+    if dtype == 'float32':
+        assert err <= 1e-3
+        assert agree >= 0.999
+    else:
+        assert err <= 2e-2
+        # bf16 rounding may flip pixels whose top-2 margin is below the error bound
+        s = np.sort(ref, axis=3)
+        clear = (s[..., -1] - s[..., -2]) > 2 * 2e-2 * scale
+        assert np.array_equal(labels[..., 0][clear], ref_lab[clear])
+    # labels are exactly the argmax of the logits the GPU produced
+    assert np.array_equal(labels[..., 0], np.argmax(logits, axis=3))
+    # colour map: bit-exact given the label map
+    h, w = in_shape[1], in_shape[2]
+    assert np.array_equal(colors, O.map_to_colored_labels(labels[..., 0], CITYSCAPES_LABEL_COLORS)[:, :h, :w])
+    # the hipGraph replay gives the same result as the eager launch sequence
+    cg.launch()
+    cg.sync()
+    assert np.array_equal(cg.fetch(outs[1]), labels)
+
+
+def test_classifier_commute_is_exact_enough():
+    """Moving the 1x1 classifier in front of the x2 zoom changes logits by
+    rounding only."""
+    from fss import plan
+    case = CASES[0]
+    g, cfg, outs, weights = build(*case)
+    img = np.random.default_rng(1).integers(0, 256, case[4]).astype(np.uint8)
+    a = plan.CompiledGraph(g, outs, weights, dtype='float32', commute_classifier=True).run(img)[0]
+    b = plan.CompiledGraph(g, outs, weights, dtype='float32', commute_classifier=False).run(img)[0]
+    assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
+
+
+def test_inference_session_matches_oracle():
+    """libs.exporter surface: uint8 HWC image in, float32 [1,h,w,3] colours out."""
+    from libs import exporter
+    from libs.constants import CITYSCAPES_LABEL_COLORS, CITYSCAPES_LABEL_IDS
+    from fss import graph as G, synth
+    from google.protobuf import text_format
+    from protos import pipeline_pb2
+    from builders import model_builder
+    cfg = pipeline_pb2.PipelineConfig()
+    text_format.Merge(CFG % dict(arch='icnet', ext='dilated_resnet50', fs=1.0,
+                                 pf=[1.0, 2.0, 3.0, 4.0], h=257, w=513), cfg)
+    img = np.random.default_rng(2).integers(0, 256, (256, 512, 3)).astype(np.uint8)
+    for table in (CITYSCAPES_LABEL_COLORS, CITYSCAPES_LABEL_IDS):
+        g = G.reset_default_graph()
+        _, model = model_builder.build(cfg.model, is_training=False)
+        outputs, placeholder = exporter.deploy_segmentation_inference_graph(
+            model=model, input_shape=[256, 512, 3], pad_to_shape=[257, 513], label_color_map=table)
+        weights = synth.make_weights(g.variables)
+        sess = exporter.Session(outputs, placeholder, weights, dtype='float32')
+        got = sess.run(img)
+        P = nets.Params(weights)
+        ref = nets.inference_outputs(lambda x: nets.icnet_predict(P, x), img, (256, 512, 3),
+                                     (257, 513), table)
+        assert got.shape == ref.shape == (1, 256, 512, len(table[0])) and got.dtype == np.float32
+        assert (np.all(got == ref, axis=-1)).mean() >= 0.999
