@@ -4,29 +4,40 @@
 //   K = kh*kw*cin with k = (r*kw + s)*cin + c.
 //
 // A is never materialised: every 16-byte chunk of an A row is cin-contiguous
-// in the NHWC input, so a thread gathers it with one predicated 16-byte load
-// (zero fill for padding taps, rows past M and k past K).  B is the packed
-// weight matrix Wp[cout_pad][k_pad] (K contiguous), so both operands land in
-// LDS as rows of BKB data bytes + 16 pad bytes; that row stride keeps the
-// ds_read_b128 fragment reads bank-conflict free.  One LDS byte layout serves
-// both dtypes: lane (r = lane&31, h = lane>>5) reads 16 bytes at 32*s + 16*h of
-// row r, which is 8 consecutive k for v_mfma_f32_32x32x16_bf16 and 4 k values
-// (consumed by 4 x v_mfma_f32_32x32x2_f32, with the same k permutation on both
-// operands) for float.
+// in the NHWC input, so one lane gathers it with one 16-byte load whose source
+// address is the tap's pixel (or a zero page for padding taps, rows past M and
+// k past K).  B is the packed weight matrix Wp[cout_pad][k_pad] (K contiguous).
 //
-// Global -> register -> LDS staging is double buffered: the loads of tile t+1
-// are issued before the MFMAs of tile t and written to the other LDS buffer
-// after them, one barrier per K tile.
+// Staging is LDS-DMA (global_load_lds_dwordx4): each wave instruction drops 64
+// chunks = 1 KiB of consecutive LDS bytes, so a stage is an unpadded image of
+// BM (resp. BN) rows x BKB bytes.  Bank conflicts of the ds_read_b128 fragment
+// reads are removed by an XOR swizzle of the 16-byte chunk index with bits of
+// the row index, applied on the SOURCE side of the DMA (which lane fetches which
+// logical chunk) and again on the read address.  NSTAGE stages form a ring: the
+// loads of tile t+NSTAGE-1 are issued before the MFMAs of tile t, and a counted
+// s_waitcnt vmcnt + one s_barrier per K tile is all the synchronisation.  The
+// DMA is issued from inline asm, so the compiler neither counts nor drains it.
 //
-// Epilogue: + bias (folded batch norm shift / conv bias), + residual,
-// activation, store with an output pixel stride (so a branch can write into a
-// channel slice of a concat buffer).
+// One LDS byte layout serves both dtypes: lane (r = lane&31, h = lane>>5) reads
+// the 16 bytes of logical chunk 2*s + h of row r, which is 8 consecutive k for
+// v_mfma_f32_32x32x16_bf16 and 4 k values (consumed by 4 x
+// v_mfma_f32_32x32x2_f32, with the same k permutation on both operands) for
+// float.
+//
+// Epilogue: each wave transposes its accumulators through LDS (32 rows at a
+// time) so that bias / residual / activation run on, and the stores write,
+// 16-byte row-contiguous pieces (whole 128-byte lines per row segment), with an
+// output pixel stride so a branch can write into a channel slice of a concat
+// buffer.
 #include "fss_common.h"
 
 namespace fss {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+// 16 zero bytes every padding tap is fetched from.
+__device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4] = {0u, 0u, 0u, 0u};
 
 struct ConvArgs {
   const void* x;
@@ -54,25 +65,50 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB>
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to the
+// 1 KiB of LDS starting at the wave-uniform byte address `lds_dst`.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt out of range");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
 conv_igemm_kernel(const ConvArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
-  constexpr int CPR = BKB / 16;             // chunks per tile row
+  constexpr int CPR = BKB / 16;             // chunks per tile row (4 or 8)
   constexpr int BK = CPR * EPC;             // K elements per tile
-  constexpr int LROW = BKB + 16;            // LDS row stride in bytes
   constexpr int A_CHUNKS = BM * CPR, B_CHUNKS = BN * CPR;
-  constexpr int A_IT = (A_CHUNKS + NT - 1) / NT, B_IT = (B_CHUNKS + NT - 1) / NT;
+  constexpr int A_IT = A_CHUNKS / NT, B_IT = B_CHUNKS / NT;
+  constexpr int LOADS = A_IT + B_IT;        // DMA pieces per wave per stage
   constexpr int RSTEP = NT / CPR;           // row step between a thread's chunks
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / 32, NI = WTN / 32;
-  static_assert(NT % CPR == 0, "thread count must be a multiple of chunks per row");
+  constexpr int STAGE_BYTES = (BM + BN) * BKB;
+  constexpr int SWZ_SHIFT = CPR == 4 ? 2 : 1;   // rows that share a bank window
+  static_assert(CPR == 4 || CPR == 8, "BKB must be 64 or 128");
+  static_assert(A_CHUNKS % NT == 0 && B_CHUNKS % NT == 0, "tile must split evenly over threads");
+  static_assert(RSTEP % 32 == 0, "row step must keep the swizzle term lane-invariant");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
+  static_assert(NSTAGE >= 2 && (NSTAGE - 2) * LOADS <= 63, "ring too deep for vmcnt");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;                       // [2][BM][LROW]
-  char* sB = smem + 2 * BM * LROW;       // [2][BN][LROW]
+  const unsigned smem_base =
+      (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give
   // each XCD a contiguous range of tiles; n-tiles of one m-tile are adjacent.
@@ -82,11 +118,14 @@ conv_igemm_kernel(const ConvArgs a) {
   const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
 
   const int tid = threadIdx.x;
-  const int chunk = tid % CPR;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int row0 = tid / CPR;
+  // this lane fills physical chunk (tid % CPR) of its rows with logical chunk `chunk`
+  const int chunk = (tid % CPR) ^ ((row0 >> SWZ_SHIFT) & (CPR - 1));
 
   const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ wgt = reinterpret_cast<const T*>(a.w);
+  const void* zero_src = reinterpret_cast<const void*>(g_zero_chunk);
 
   // per-row gather state
   const T* rbase[A_IT];
@@ -94,9 +133,8 @@ conv_igemm_kernel(const ConvArgs a) {
   const int HoWo = a.Ho * a.Wo;
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int row = row0 + i * RSTEP;
-    const int m = tile_m * BM + row;
-    if (row < BM && m < a.M) {
+    const int m = tile_m * BM + row0 + i * RSTEP;
+    if (m < a.M) {
       const int n = m / HoWo;
       const int rem = m - n * HoWo;
       const int oh = rem / a.Wo;
@@ -110,58 +148,52 @@ conv_igemm_kernel(const ConvArgs a) {
       rbase[i] = xg;
     }
   }
-  // position of this thread's chunk inside the filter: channel kc of tap (kr, ks)
+  // position of this lane's logical chunk inside the filter: channel kc of tap (kr, ks)
   int kc = chunk * EPC, kr = 0, ks = 0;
   while (kc >= a.Cin) {
     kc -= a.Cin;
     if (++ks == a.KW) { ks = 0; ++kr; }
   }
-
   const T* wrow[B_IT];
 #pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
-    const int row = row0 + i * RSTEP;
-    wrow[i] = wgt + (size_t)(tile_n * BN + (row < BN ? row : 0)) * a.Kpad + chunk * EPC;
-  }
+  for (int i = 0; i < B_IT; ++i)
+    wrow[i] = wgt + (size_t)(tile_n * BN + row0 + i * RSTEP) * a.Kpad + chunk * EPC;
 
-  uint4 ra[A_IT], rb[B_IT];
-  auto load_tile = [&](int kt) {
+  const int KT = a.Kpad / BK;
+
+  // issues the LOADS DMA pieces of K tile `kt` into ring slot `slot`; tiles past
+  // KT fetch zeros so every wave always has the same number of pieces in flight
+  auto issue = [&](int kt, int slot) {
+    const unsigned dstA = smem_base + slot * STAGE_BYTES + wave * 1024;
+    const unsigned dstB = dstA + BM * BKB;
+    const int dr = kr * a.dil, ds = ks * a.dil;
+    const bool k_ok = kr < a.KH;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int ih = ih0[i] + kr * a.dil;
-      const int iw = iw0[i] + ks * a.dil;
-      const bool ok = (kr < a.KH) && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *reinterpret_cast<const uint4*>(rbase[i] + ((size_t)ih * a.W + iw) * a.Cin + kc);
-      ra[i] = v;
+      const int ih = ih0[i] + dr, iw = iw0[i] + ds;
+      const bool ok = k_ok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
+      const void* src = ok ? (const void*)(rbase[i] + ((size_t)ih * a.W + iw) * a.Cin + kc) : zero_src;
+      glds16(src, dstA + i * (NT * 16));
     }
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i)
-      rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + (size_t)kt * BK);
+    for (int i = 0; i < B_IT; ++i) {
+      const void* src = kt < KT ? (const void*)(wrow[i] + (size_t)kt * BK) : zero_src;
+      glds16(src, dstB + i * (NT * 16));
+    }
     kc += BK;
     while (kc >= a.Cin) {
       kc -= a.Cin;
       if (++ks == a.KW) { ks = 0; ++kr; }
     }
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int row = row0 + i * RSTEP;
-      if (A_CHUNKS % NT == 0 || row < BM)
-        *reinterpret_cast<uint4*>(sA + (buf * BM + row) * LROW + chunk * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const int row = row0 + i * RSTEP;
-      if (B_CHUNKS % NT == 0 || row < BN)
-        *reinterpret_cast<uint4*>(sB + (buf * BN + row) * LROW + chunk * 16) = rb[i];
-    }
-  };
 
-  const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, lh = lane >> 5;
+  const int swz = (l31 >> SWZ_SHIFT) & (CPR - 1);
+  // byte offset, inside a row, of the fragment this lane reads at k step s
+  int frag_off[BKB / 32];
+#pragma unroll
+  for (int s = 0; s < BKB / 32; ++s) frag_off[s] = ((2 * s + lh) ^ swz) * 16;
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -171,64 +203,118 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int KT = a.Kpad / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
 
+  int slot = 0, fill = NSTAGE - 1;
   for (int kt = 0; kt < KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < KT) load_tile(kt + 1);
-    const char* pa = sA + (cur * BM + wm * WTM + l31) * LROW + lh * 16;
-    const char* pb = sB + (cur * BN + wn * WTN + l31) * LROW + lh * 16;
+    wait_vmcnt<(NSTAGE - 2) * LOADS>();      // this wave's pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();            // ... and everybody else's; slot `fill` is free
+    issue(kt + NSTAGE - 1, fill);
+    const char* pa = smem + slot * STAGE_BYTES + (wm * WTM + l31) * BKB;
+    const char* pb = smem + slot * STAGE_BYTES + BM * BKB + (wn * WTN + l31) * BKB;
 #pragma unroll
     for (int s = 0; s < BKB / 32; ++s) {
       uint4 fa[MI], fb[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
-        fa[i] = *reinterpret_cast<const uint4*>(pa + i * 32 * LROW + s * 32);
+        fa[i] = *reinterpret_cast<const uint4*>(pa + i * 32 * BKB + frag_off[s]);
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        fb[j] = *reinterpret_cast<const uint4*>(pb + j * 32 * LROW + s * 32);
+        fb[j] = *reinterpret_cast<const uint4*>(pb + j * 32 * BKB + frag_off[s]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
     }
-    if (kt + 1 < KT) store_tile(cur ^ 1);
-    __syncthreads();
+    slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    fill = fill + 1 == NSTAGE ? 0 : fill + 1;
   }
+  wait_vmcnt<0>();                           // drain the zero-fill tail pieces
+  __syncthreads();                           // everyone is done with the ring
 
-  // epilogue.  Accumulator register r of lane l holds
-  // C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] of its 32x32 tile.
+  // ---- epilogue: per wave, 32 rows at a time through LDS.
+  // Accumulator register r of lane l holds
+  //   C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] of its 32x32 tile.
+  constexpr int SROW = WTN + 4;              // staging row stride in floats
+  static_assert(WAVES_M * WAVES_N * 32 * SROW * 4 <= NSTAGE * STAGE_BYTES,
+                "epilogue staging does not fit in the ring");
+  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SROW);
   TO* __restrict__ yg = reinterpret_cast<TO*>(a.y);
   const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+  const int n_base = tile_n * BN + wn * WTN;
+  constexpr int QPR = WTN / 4;               // float4 groups per staged row
+  constexpr int PASSES = 32 * QPR / 64;      // float4 groups per lane per 32-row slab
+  // branch-free activation: none / relu / relu6 as a clamp to [lo, hi]
+  const float act_lo = a.act == FSS_ACT_NONE ? -INFINITY : 0.f;
+  const float act_hi = a.act == FSS_ACT_RELU6 ? 6.f : INFINITY;
+  const bool vec_ok = ((a.y_ld & 3) == 0) && ((a.Cout & 3) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
+                      (rg == nullptr ||
+                       (((a.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.res) & 15) == 0)));
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int n = tile_n * BN + wn * WTN + j * 32 + l31;
-    const bool n_ok = n < a.Cout;
-    const float bias = (n_ok && a.bias) ? a.bias[n] : 0.f;
+  for (int i = 0; i < MI; ++i) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+    for (int j = 0; j < NI; ++j) {
+      const int n = n_base + j * 32 + l31;
+      const float bias = (a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = tile_m * BM + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n_ok && m < a.M) {
-          float v = acc[i][j][r] + bias;
-          if (rg) v += ElemTraits<T>::load(rg + (size_t)m * a.res_ld + n);
-          v = apply_act(v, a.act);
-          ElemTraits<TO>::store(yg + (size_t)m * a.y_ld + n, v);
+      for (int r = 0; r < 16; ++r)
+        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SROW + j * 32 + l31] = acc[i][j][r] + bias;
+    }
+    __syncthreads();
+    const int m_base = tile_m * BM + wm * WTM + i * 32;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int g = lane + p * 64;
+      const int row = g / QPR, c4 = (g % QPR) * 4;
+      const int m = m_base + row, n = n_base + c4;
+      if (m < a.M && n < a.Cout) {
+        const float4 v4 = *reinterpret_cast<const float4*>(stage + row * SROW + c4);
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        TO* dst = yg + (size_t)m * a.y_ld + n;
+        if (vec_ok) {
+          if (rg != nullptr) {
+            const T* rp = rg + (size_t)m * a.res_ld + n;
+            if constexpr (sizeof(T) == 4) {
+              const float4 r4 = *reinterpret_cast<const float4*>(rp);
+              v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            } else {
+              const uint2 r2 = *reinterpret_cast<const uint2*>(rp);
+              v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+              v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
+          if constexpr (sizeof(TO) == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 o;
+            o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(dst) = o;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (n + e < a.Cout) {
+              float t = v[e];
+              if (rg != nullptr) t += ElemTraits<T>::load(rg + (size_t)m * a.res_ld + n + e);
+              ElemTraits<TO>::store(dst + e, fminf(fmaxf(t, act_lo), act_hi));
+            }
+          }
         }
       }
     }
+    __syncthreads();
   }
 }
 
-template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB>
+template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE>
 static int launch_conv(ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int LROW = BKB + 16;
-  constexpr size_t smem = 2 * (size_t)(BM + BN) * LROW;
+  constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BKB;
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cout, BN);
   const long long blocks = (long long)a.tiles_m * a.tiles_n;
@@ -236,13 +322,17 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     set_error("fss_conv2d_nhwc: grid out of range");
     return 2;
   }
-  auto kern = conv_igemm_kernel<T, TO, BM, BN, WAVES_M, WAVES_N, BKB>;
+  auto kern = conv_igemm_kernel<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE>;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) {
-      set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
-      return 1;
+    static bool attr_set = false;   // per instantiation
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) {
+        set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        return 1;
+      }
+      attr_set = true;
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), smem, stream, a);
@@ -259,11 +349,11 @@ static int dispatch_conv(ConvArgs& a, hipStream_t stream) {
   // Tile choice: widest N tile the layer fills; drop to 64-row tiles when the
   // 128-row grid would leave most of the 256 CUs idle.
   const int n_cols = a.Cout;
-  if (n_cols <= 32) return launch_conv<T, TO, 128, 32, 4, 1, 64>(a, stream);
-  if (n_cols <= 64) return launch_conv<T, TO, 128, 64, 2, 2, 64>(a, stream);
+  if (n_cols <= 32) return launch_conv<T, TO, 128, 32, 2, 1, 64, 4>(a, stream);
+  if (n_cols <= 64) return launch_conv<T, TO, 128, 64, 2, 2, 64, 4>(a, stream);
   const long long big = (long long)ceil_div(a.M, 128) * ceil_div(n_cols, 128);
-  if (big >= 192) return launch_conv<T, TO, 128, 128, 2, 2, 64>(a, stream);
-  return launch_conv<T, TO, 64, 64, 2, 2, 64>(a, stream);
+  if (big >= 192) return launch_conv<T, TO, 128, 128, 2, 2, 64, 4>(a, stream);
+  return launch_conv<T, TO, 64, 64, 2, 2, 64, 4>(a, stream);
 }
 
 }  // namespace fss
