@@ -281,10 +281,10 @@ __global__ void preprocess_kernel(const uint8_t* __restrict__ x, T* __restrict__
 }
 
 // ------------------------------------------------------- upsample + argmax
-template <int MAXC>
+// Generic form: one thread per output pixel.
 __global__ void upsample_argmax_kernel(const float* __restrict__ x, uint8_t* __restrict__ labels,
                                        float* __restrict__ logits_out, int N, int H, int W, int C,
-                                       int Ho, int Wo, float sh, float sw) {
+                                       int x_ld, int Ho, int Wo, float sh, float sw) {
   const size_t total = (size_t)N * Ho * Wo;
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
@@ -296,11 +296,11 @@ __global__ void upsample_argmax_kernel(const float* __restrict__ x, uint8_t* __r
   float ly, lx;
   interp_coord(oh, sh, H, y0, y1, ly);
   interp_coord(ow, sw, W, x0, x1, lx);
-  const float* b = x + (size_t)n * H * W * C;
-  const float* ptl = b + ((size_t)y0 * W + x0) * C;
-  const float* ptr = b + ((size_t)y0 * W + x1) * C;
-  const float* pbl = b + ((size_t)y1 * W + x0) * C;
-  const float* pbr = b + ((size_t)y1 * W + x1) * C;
+  const float* b = x + (size_t)n * H * W * x_ld;
+  const float* ptl = b + ((size_t)y0 * W + x0) * x_ld;
+  const float* ptr = b + ((size_t)y0 * W + x1) * x_ld;
+  const float* pbl = b + ((size_t)y1 * W + x0) * x_ld;
+  const float* pbr = b + ((size_t)y1 * W + x1) * x_ld;
   float best = -INFINITY;
   int arg = 0;
   for (int c = 0; c < C; ++c) {
@@ -312,6 +312,67 @@ __global__ void upsample_argmax_kernel(const float* __restrict__ x, uint8_t* __r
     if (v > best || c == 0) { best = v; arg = c; }
   }
   labels[idx] = (uint8_t)arg;
+}
+
+// Power-of-two align_corners zoom Z (out = (in-1)*Z + 1): one thread per INPUT
+// cell computes the Z x Z output pixels whose top-left neighbour it is, reading
+// its 2x2 neighbourhood once, 4 channels per 16-byte load.  Source coordinates
+// are exact here (scale = 1/Z), so lerp weights are (i/Z, j/Z).
+template <int Z>
+__global__ void upsample_argmax_zoom_kernel(const float* __restrict__ x,
+                                            uint8_t* __restrict__ labels, int N, int H, int W,
+                                            int C, int x_ld, int Ho, int Wo) {
+  const size_t total = (size_t)N * H * W;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  size_t p = idx;
+  const int x0 = (int)(p % W); p /= W;
+  const int y0 = (int)(p % H);
+  const int n = (int)(p / H);
+  const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+  const float* b = x + (size_t)n * H * W * x_ld;
+  const float4* ptl = reinterpret_cast<const float4*>(b + ((size_t)y0 * W + x0) * x_ld);
+  const float4* ptr = reinterpret_cast<const float4*>(b + ((size_t)y0 * W + x1) * x_ld);
+  const float4* pbl = reinterpret_cast<const float4*>(b + ((size_t)y1 * W + x0) * x_ld);
+  const float4* pbr = reinterpret_cast<const float4*>(b + ((size_t)y1 * W + x1) * x_ld);
+  float best[Z][Z];
+  int arg[Z][Z];
+#pragma unroll
+  for (int i = 0; i < Z; ++i)
+#pragma unroll
+    for (int j = 0; j < Z; ++j) { best[i][j] = -INFINITY; arg[i][j] = 0; }
+  const int groups = (C + 3) >> 2;
+  for (int g = 0; g < groups; ++g) {
+    const float4 tl4 = ptl[g], tr4 = ptr[g], bl4 = pbl[g], br4 = pbr[g];
+    const float tl[4] = {tl4.x, tl4.y, tl4.z, tl4.w}, tr[4] = {tr4.x, tr4.y, tr4.z, tr4.w};
+    const float bl[4] = {bl4.x, bl4.y, bl4.z, bl4.w}, br[4] = {br4.x, br4.y, br4.z, br4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = g * 4 + e;
+      if (c < C) {
+#pragma unroll
+        for (int j = 0; j < Z; ++j) {
+          const float lx = (float)j * (1.0f / Z);
+          const float top = tl[e] + (tr[e] - tl[e]) * lx;
+          const float bot = bl[e] + (br[e] - bl[e]) * lx;
+#pragma unroll
+          for (int i = 0; i < Z; ++i) {
+            const float v = top + (bot - top) * ((float)i * (1.0f / Z));
+            if (v > best[i][j] || c == 0) { best[i][j] = v; arg[i][j] = c; }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < Z; ++i) {
+    const int oh = y0 * Z + i;
+    if (oh >= Ho) break;
+    uint8_t* row = labels + ((size_t)n * Ho + oh) * Wo + (size_t)x0 * Z;
+#pragma unroll
+    for (int j = 0; j < Z; ++j)
+      if (x0 * Z + j < Wo) row[j] = (uint8_t)arg[i][j];
+  }
 }
 
 // ----------------------------------------------------------------- label LUT
@@ -607,14 +668,31 @@ int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho, i
 }
 
 int fss_upsample_argmax(const float* logits, uint8_t* labels, float* logits_out, int n, int h,
-                        int wd, int c, int ho, int wo, void* stream) {
+                        int wd, int c, int x_ld, int ho, int wo, void* stream) {
   FSS_REQUIRE(logits && labels, "null argument");
   FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0, "bad shape");
   FSS_REQUIRE(c > 0 && c <= 256, "class count must be in [1, 256]");
+  FSS_REQUIRE(x_ld >= c, "x_ld < c");
+  hipStream_t s = (hipStream_t)stream;
+  // exact power-of-two zoom with 16-byte readable pixels: one thread per input cell
+  const int zh = h > 1 ? (ho - 1) / (h - 1) : 0, zw = wd > 1 ? (wo - 1) / (wd - 1) : 0;
+  const bool pow2 = zh == zw && (zh == 2 || zh == 4 || zh == 8) && (ho - 1) == zh * (h - 1) &&
+                    (wo - 1) == zw * (wd - 1);
+  if (pow2 && logits_out == nullptr && (x_ld & 3) == 0 && ((c + 3) & ~3) <= x_ld &&
+      ((uintptr_t)logits & 15) == 0) {
+    const size_t cells = (size_t)n * h * wd;
+#define FSS_ZOOM(Z)                                                                              \
+  hipLaunchKernelGGL(upsample_argmax_zoom_kernel<Z>, dim3(grid_for(cells)), dim3(kBlock), 0, s, \
+                     logits, labels, n, h, wd, c, x_ld, ho, wo)
+    if (zh == 2) FSS_ZOOM(2); else if (zh == 4) FSS_ZOOM(4); else FSS_ZOOM(8);
+#undef FSS_ZOOM
+    FSS_LAUNCH_CHECK();
+    return 0;
+  }
   const float sh = resize_scale(h, ho, 1), sw = resize_scale(wd, wo, 1);
   const size_t total = (size_t)n * ho * wo;
-  hipLaunchKernelGGL(upsample_argmax_kernel<0>, dim3(grid_for(total)), dim3(kBlock), 0,
-                     (hipStream_t)stream, logits, labels, logits_out, n, h, wd, c, ho, wo, sh, sw);
+  hipLaunchKernelGGL(upsample_argmax_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, logits,
+                     labels, logits_out, n, h, wd, c, x_ld, ho, wo, sh, sw);
   FSS_LAUNCH_CHECK();
   return 0;
 }

@@ -65,7 +65,7 @@ PROTOTYPES = {
     'fss_copy_channels': (c_int, [c_void_p, c_int, c_void_p, c_int, c_size_t, c_int, c_int, c_void_p]),
     'fss_preprocess_u8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_float_p, c_float_p, c_int, c_void_p]),
-    'fss_upsample_argmax': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    'fss_upsample_argmax': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'fss_label_lut': (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'fss_confusion_accumulate': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
 }

@@ -318,7 +318,14 @@ class CompiledGraph(object):
         self.keepalive.append(wdev)
         bdev = self._dev_f32(bias)
         self.param_bytes += cout * kh * kw * cin * _ESZ[in_dt]
-        out = Val(self._alloc(ln.shape, out_dt), ln.shape, out_dt)
+        if a['biases'] is not None:
+            # logits: pixel stride rounded up to 16 bytes so later kernels read float4s;
+            # the pad channel is zero and never looked at
+            pc_out = (cout + 3) // 4 * 4
+            out = Val(torch.zeros((n, ho, wo, pc_out), dtype=torch.float32, device=self.device),
+                      ln.shape, out_dt, phys_c=pc_out)
+        else:
+            out = Val(self._alloc(ln.shape, out_dt), ln.shape, out_dt)
         self.vals[result] = out
         if result is not ln:
             self.vals[ln] = out
@@ -519,7 +526,7 @@ class CompiledGraph(object):
                      (n, ho, wo, 1), 'u8')
         self.vals[ln] = labels
         self._emit('argmax', 'upsample_argmax', 'fss_upsample_argmax',
-                   (x.ptr, labels.ptr, full_ptr, n, h, w, c, ho, wo, self.sh),
+                   (x.ptr, labels.ptr, full_ptr, n, h, w, c, x.ld, ho, wo, self.sh),
                    nbytes=n * h * w * c * 4 + n * ho * wo + (n * ho * wo * c * 4 if full_ptr else 0))
 
     def _l_lut(self, ln):

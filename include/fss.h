@@ -164,14 +164,15 @@ int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho,
                       int wo, int c_out, const float* mean3, const float* scale3,
                       int dtype, void* stream);
 
-/* Bilinear (align_corners) upsample of float logits [n,h,w,c] to [n,ho,wo]
- * fused with argmax over channels (lowest index wins ties); labels are uint8.
- * If `logits_out` is non-NULL the upsampled logits [n,ho,wo,c] are stored too.
+/* Bilinear (align_corners) upsample of float logits [n,h,w,c] (pixel stride
+ * x_ld >= c floats) to [n,ho,wo] fused with argmax over channels (lowest index
+ * wins ties); labels are uint8.  If `logits_out` is non-NULL the upsampled
+ * logits [n,ho,wo,c] (dense) are stored too.
  * Replaces _dynamic_interpolation(z_factor) + tf.argmax(.., 3)
  * (architectures/icnet_architecture.py:142-144, libs/exporter.py:41,
  * libs/evaluator.py:65-72,85). */
 int fss_upsample_argmax(const float* logits, uint8_t* labels, float* logits_out,
-                        int n, int h, int wd, int c, int ho, int wo, void* stream);
+                        int n, int h, int wd, int c, int x_ld, int ho, int wo, void* stream);
 
 /* y[n,i,j,:] = table[labels[n,i,j]] for i<ho, j<wo (top-left crop).
  * Replaces one_hot @ color_table + crop_to_bounding_box

@@ -285,8 +285,8 @@ def test_upsample_argmax_lut_confusion():
     xd = torch.from_numpy(x).cuda()
     lab = torch.empty((n, ho, wo), dtype=torch.uint8, device='cuda')
     full = torch.empty((n, ho, wo, c), dtype=torch.float32, device='cuda')
-    _call('fss_upsample_argmax', xd.data_ptr(), lab.data_ptr(), full.data_ptr(), n, h, wd, c, ho, wo,
-          None)
+    _call('fss_upsample_argmax', xd.data_ptr(), lab.data_ptr(), full.data_ptr(), n, h, wd, c, c, ho,
+          wo, None)
     got_full = full.cpu().numpy()
     _close(got_full, up, 2e-6, 'upsampled logits')
     got = lab.cpu().numpy().astype(np.int64)
@@ -299,8 +299,27 @@ def test_upsample_argmax_lut_confusion():
     assert got[0, 0, 0] == ref[0, 0, 0]
     # same-size call = plain argmax (tie rows included): bit-exact
     lab2 = torch.empty((n, h, wd), dtype=torch.uint8, device='cuda')
-    _call('fss_upsample_argmax', xd.data_ptr(), lab2.data_ptr(), None, n, h, wd, c, h, wd, None)
+    _call('fss_upsample_argmax', xd.data_ptr(), lab2.data_ptr(), None, n, h, wd, c, c, h, wd, None)
     assert np.array_equal(lab2.cpu().numpy().astype(np.int64), O.argmax_channels(x))
+    # power-of-two zoom fast path (pixel stride 20 floats): source coordinates are exact,
+    # so labels are bit-exact against the oracle's argmax wherever its float32 logits
+    # have no exact tie broken differently by fma contraction
+    xp = np.zeros((n, h, wd, 20), np.float32)
+    xp[..., :c] = x
+    xp[..., c] = 1e9               # the pad channel must never win
+    xpd = torch.from_numpy(xp).cuda()
+    for z in (2, 4, 8):
+        hz, wz = (h - 1) * z + 1, (wd - 1) * z + 1
+        upz = O.resize_bilinear(x, hz, wz, True)
+        labz = torch.full((n, hz, wz), 255, dtype=torch.uint8, device='cuda')
+        _call('fss_upsample_argmax', xpd.data_ptr(), labz.data_ptr(), None, n, h, wd, c, 20, hz, wz,
+              None)
+        gz = labz.cpu().numpy().astype(np.int64)
+        sz = np.sort(upz, axis=3)
+        clearz = (sz[..., -1] - sz[..., -2]) > 1e-5
+        assert gz.max() < c
+        assert np.array_equal(gz[clearz], O.argmax_channels(upz)[clearz])
+        assert clearz.mean() > 0.4
     # colour LUT with crop
     from libs.constants import CITYSCAPES_LABEL_COLORS, CITYSCAPES_LABEL_IDS
     for table in (CITYSCAPES_LABEL_COLORS, CITYSCAPES_LABEL_IDS):
