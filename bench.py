@@ -182,8 +182,8 @@ def main():
                 for p in prof:
                     tf = p['flops'] / (p['ms'] * 1e-3) / 1e12 if p['ms'] > 0 else 0
                     gb = p['bytes'] / (p['ms'] * 1e-3) / 1e9 if p['ms'] > 0 else 0
-                    f.write('%-10s %-70s %8.4f ms %8.1f TFLOP/s %8.1f GB/s\n'
-                            % (p['kind'], p['name'], p['ms'], tf, gb))
+                    f.write('%-10s %-70s %8.4f ms %8.1f TFLOP/s %8.1f GB/s cfg=%s\n'
+                            % (p['kind'], p['name'], p['ms'], tf, gb, p.get('config')))
     del cg
     if rank == 0 and world == 1 and not args.no_latency:
         # bs=1 latency of the same model (median wall time of a launch + sync)

@@ -66,16 +66,15 @@ template <> struct Mma<float> {
 };
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to the
-// 1 KiB of LDS starting at the wave-uniform byte address `lds_dst`.
+// 1 KiB of LDS starting at the wave-uniform byte address `lds_dst`.  M0 (the DMA's
+// LDS base) is written and consumed inside the one statement; nothing else in
+// this translation unit reads M0.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\t"
+      "s_mov_b32 m0, %1\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
+      "global_load_lds_dwordx4 %0, off"
+      :
       : "v"(gsrc), "s"(lds_dst)
       : "memory");
 }
@@ -85,7 +84,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE>
+// ALIGNED: cin is a multiple of the K tile, so a tile never straddles two filter
+// taps and the tap walk is wave-uniform (scalar) instead of per lane.
+template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE,
+          bool ALIGNED>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
 conv_igemm_kernel(const ConvArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -127,63 +129,100 @@ conv_igemm_kernel(const ConvArgs a) {
   const T* __restrict__ wgt = reinterpret_cast<const T*>(a.w);
   const void* zero_src = reinterpret_cast<const void*>(g_zero_chunk);
 
-  // per-row gather state
-  const T* rbase[A_IT];
-  int ih0[A_IT], iw0[A_IT];
+  const int KT = a.Kpad / BK;
   const int HoWo = a.Ho * a.Wo;
+
+  // ---- per-row gather state
+  // ALIGNED: rptr = address of this lane's chunk at tap (0,0), tapmask bit t = tap t
+  //          of this row reads a real pixel.  Otherwise: explicit coordinates.
+  const char* rptr[A_IT];
+  unsigned long long tapmask[A_IT];
+  int ih0[A_IT], iw0[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int m = tile_m * BM + row0 + i * RSTEP;
-    if (m < a.M) {
-      const int n = m / HoWo;
+    int n = 0, oh = 0, ow = 0;
+    const bool row_ok = m < a.M;
+    if (row_ok) {
+      n = m / HoWo;
       const int rem = m - n * HoWo;
-      const int oh = rem / a.Wo;
-      const int ow = rem - oh * a.Wo;
-      ih0[i] = oh * a.stride - a.pad_t;
-      iw0[i] = ow * a.stride - a.pad_l;
-      rbase[i] = xg + (size_t)n * a.H * a.W * a.Cin;
-    } else {
-      ih0[i] = -(1 << 28);
-      iw0[i] = -(1 << 28);
-      rbase[i] = xg;
+      oh = rem / a.Wo;
+      ow = rem - oh * a.Wo;
+    }
+    ih0[i] = row_ok ? oh * a.stride - a.pad_t : -(1 << 28);
+    iw0[i] = row_ok ? ow * a.stride - a.pad_l : -(1 << 28);
+    const long long pix = ((long long)n * a.H + (row_ok ? ih0[i] : 0)) * a.W + (row_ok ? iw0[i] : 0);
+    rptr[i] = reinterpret_cast<const char*>(xg) + (pix * a.Cin + chunk * EPC) * (long long)sizeof(T);
+    tapmask[i] = 0;
+    if constexpr (ALIGNED) {
+      for (int r = 0, t = 0; r < a.KH; ++r)
+        for (int sx = 0; sx < a.KW; ++sx, ++t) {
+          const bool ok = ((unsigned)(ih0[i] + r * a.dil) < (unsigned)a.H) &&
+                          ((unsigned)(iw0[i] + sx * a.dil) < (unsigned)a.W);
+          tapmask[i] |= (unsigned long long)ok << t;
+        }
     }
   }
-  // position of this lane's logical chunk inside the filter: channel kc of tap (kr, ks)
-  int kc = chunk * EPC, kr = 0, ks = 0;
-  while (kc >= a.Cin) {
-    kc -= a.Cin;
-    if (++ks == a.KW) { ks = 0; ++kr; }
-  }
-  const T* wrow[B_IT];
+  const char* wptr[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i)
-    wrow[i] = wgt + (size_t)(tile_n * BN + row0 + i * RSTEP) * a.Kpad + chunk * EPC;
+    wptr[i] = reinterpret_cast<const char*>(wgt + (size_t)(tile_n * BN + row0 + i * RSTEP) * a.Kpad +
+                                            chunk * EPC);
 
-  const int KT = a.Kpad / BK;
+  // tap walk.  ALIGNED: (cb, kr, ks) = channel base / tap of the whole tile (uniform).
+  // Otherwise: channel kc of tap (kr, ks) of this lane's logical chunk.
+  int kc = ALIGNED ? 0 : chunk * EPC, kr = 0, ks = 0;
+  if constexpr (!ALIGNED) {
+    while (kc >= a.Cin) {
+      kc -= a.Cin;
+      if (++ks == a.KW) { ks = 0; ++kr; }
+    }
+  }
 
   // issues the LOADS DMA pieces of K tile `kt` into ring slot `slot`; tiles past
   // KT fetch zeros so every wave always has the same number of pieces in flight
   auto issue = [&](int kt, int slot) {
     const unsigned dstA = smem_base + slot * STAGE_BYTES + wave * 1024;
     const unsigned dstB = dstA + BM * BKB;
-    const int dr = kr * a.dil, ds = ks * a.dil;
-    const bool k_ok = kr < a.KH;
+    if constexpr (ALIGNED) {
+      const int tap = min(kr * a.KW + ks, 63);          // bit 63 is never set
+      // byte offset of the tap inside one image: fits 32 bits (checked by the host)
+      const int tap_off = ((kr * a.dil * a.W + ks * a.dil) * a.Cin + kc) * (int)sizeof(T);
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      const int ih = ih0[i] + dr, iw = iw0[i] + ds;
-      const bool ok = k_ok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
-      const void* src = ok ? (const void*)(rbase[i] + ((size_t)ih * a.W + iw) * a.Cin + kc) : zero_src;
-      glds16(src, dstA + i * (NT * 16));
+      for (int i = 0; i < A_IT; ++i) {
+        const bool ok = (tapmask[i] >> tap) & 1ull;
+        const void* src = ok ? (const void*)(rptr[i] + tap_off) : zero_src;
+        glds16(src, dstA + i * (NT * 16));
+      }
+    } else {
+      const int dr = kr * a.dil, ds = ks * a.dil;
+      const bool k_ok = kr < a.KH;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int ih = ih0[i] + dr, iw = iw0[i] + ds;
+        const bool ok = k_ok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
+        const int off = ((dr * a.W + ds) * a.Cin + (kc - chunk * EPC)) * (int)sizeof(T);
+        const void* src = ok ? (const void*)(rptr[i] + off) : zero_src;
+        glds16(src, dstA + i * (NT * 16));
+      }
     }
+    const bool w_ok = kt < KT;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      const void* src = kt < KT ? (const void*)(wrow[i] + (size_t)kt * BK) : zero_src;
+      const void* src = w_ok ? (const void*)(wptr[i] + (size_t)kt * BKB) : zero_src;
       glds16(src, dstB + i * (NT * 16));
     }
     kc += BK;
-    while (kc >= a.Cin) {
-      kc -= a.Cin;
-      if (++ks == a.KW) { ks = 0; ++kr; }
+    if constexpr (ALIGNED) {
+      if (kc == a.Cin) {
+        kc = 0;
+        if (++ks == a.KW) { ks = 0; ++kr; }
+      }
+    } else {
+      while (kc >= a.Cin) {
+        kc -= a.Cin;
+        if (++ks == a.KW) { ks = 0; ++kr; }
+      }
     }
   };
 
@@ -311,8 +350,9 @@ conv_igemm_kernel(const ConvArgs a) {
   }
 }
 
-template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE>
-static int launch_conv(ConvArgs& a, hipStream_t stream) {
+template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE,
+          bool ALIGNED>
+static int launch_conv_impl(ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BKB;
   a.tiles_m = ceil_div(a.M, BM);
@@ -322,7 +362,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     set_error("fss_conv2d_nhwc: grid out of range");
     return 2;
   }
-  auto kern = conv_igemm_kernel<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE>;
+  auto kern = conv_igemm_kernel<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, ALIGNED>;
   if (smem > 64 * 1024) {
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -344,16 +384,58 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   return 0;
 }
 
+template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE>
+static int launch_conv(ConvArgs& a, hipStream_t stream) {
+  constexpr int BK = BKB / (int)sizeof(T);
+  if (a.Cin % BK == 0 && a.KH * a.KW <= 63)
+    return launch_conv_impl<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, true>(a, stream);
+  return launch_conv_impl<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, false>(a, stream);
+}
+
+// Tile configurations.  Every configuration is legal for every layer (tiles
+// larger than the problem only waste lanes) and all of them accumulate each
+// output element over k in the same order, so results do not depend on the
+// choice; which one is fastest depends on M, N, K and is best measured
+// (fss.plan times the candidates once per distinct layer shape).
+//   columns: BM, BN, waves M x N, bytes of K per tile row, ring stages
+#define FSS_CONV_CONFIGS(X)   \
+  X(1, 128, 128, 2, 2, 64, 4)  \
+  X(2, 128, 128, 2, 2, 64, 3)  \
+  X(3, 128, 128, 2, 2, 128, 2) \
+  X(4, 256, 128, 4, 2, 128, 2) \
+  X(5, 128, 64, 2, 2, 128, 2)  \
+  X(6, 128, 64, 2, 2, 64, 4)   \
+  X(7, 128, 64, 2, 2, 64, 3)   \
+  X(8, 128, 64, 2, 2, 64, 2)   \
+  X(9, 64, 64, 2, 2, 128, 2)   \
+  X(10, 64, 64, 2, 2, 64, 4)   \
+  X(11, 128, 32, 2, 1, 64, 4)  \
+  X(12, 128, 32, 2, 1, 64, 2)
+static constexpr int kNumConvConfigs = 12;
+
+// automatic choice when the caller does not name a configuration
+static int default_config(const ConvArgs& a) {
+  if (a.Cout <= 32) return 11;
+  if (a.K <= 256) return a.Cout <= 64 ? 6 : 8;          // short K: memory bound, favour occupancy
+  if (a.Cout <= 64) return 6;
+  const long long tiles = (long long)ceil_div(a.M, 128) * ceil_div(a.Cout, 128);
+  if (tiles >= 1024) return 3;
+  if (tiles >= 192) return 2;
+  return 9;
+}
+
 template <typename T, typename TO>
-static int dispatch_conv(ConvArgs& a, hipStream_t stream) {
-  // Tile choice: widest N tile the layer fills; drop to 64-row tiles when the
-  // 128-row grid would leave most of the 256 CUs idle.
-  const int n_cols = a.Cout;
-  if (n_cols <= 32) return launch_conv<T, TO, 128, 32, 2, 1, 64, 4>(a, stream);
-  if (n_cols <= 64) return launch_conv<T, TO, 128, 64, 2, 2, 64, 4>(a, stream);
-  const long long big = (long long)ceil_div(a.M, 128) * ceil_div(n_cols, 128);
-  if (big >= 192) return launch_conv<T, TO, 128, 128, 2, 2, 64, 4>(a, stream);
-  return launch_conv<T, TO, 64, 64, 2, 2, 64, 4>(a, stream);
+static int dispatch_conv(ConvArgs& a, int config, hipStream_t stream) {
+  if (config == 0) config = default_config(a);
+  switch (config) {
+#define FSS_CASE(ID, BM, BN, WM, WN, BKB, NS) \
+  case ID: return launch_conv<T, TO, BM, BN, WM, WN, BKB, NS>(a, stream);
+    FSS_CONV_CONFIGS(FSS_CASE)
+#undef FSS_CASE
+    default: break;
+  }
+  set_error("fss_conv2d_nhwc: unknown config");
+  return 2;
 }
 
 }  // namespace fss
@@ -370,6 +452,8 @@ extern "C" int fss_conv_pack_dims(int cin, int kh, int kw, int cout, int dtype, 
   *cout_pad = (cout + 127) / 128 * 128; // a multiple of every N tile in use
   return 0;
 }
+
+extern "C" int fss_conv_config_count(void) { return kNumConvConfigs; }
 
 extern "C" int fss_conv2d_nhwc(const fss_conv_desc* d, const void* x, const void* w_packed,
                                const float* bias, const void* residual, void* y, void* stream) {
@@ -394,6 +478,8 @@ extern "C" int fss_conv2d_nhwc(const fss_conv_desc* d, const void* x, const void
   FSS_REQUIRE(d->y_ld >= d->cout, "y_ld < cout");
   FSS_REQUIRE(residual == nullptr || d->res_ld >= d->cout, "res_ld < cout");
   FSS_REQUIRE((long long)d->n * d->ho * d->wo < 0x7fffffffLL, "too many output pixels");
+  FSS_REQUIRE((long long)d->h * d->w * d->cin * (d->in_dtype == FSS_F32 ? 4 : 2) < 0x7fffffffLL,
+              "one input image must be smaller than 2 GiB");
   FSS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0, "unaligned pointer");
 
   ConvArgs a;
@@ -406,7 +492,8 @@ extern "C" int fss_conv2d_nhwc(const fss_conv_desc* d, const void* x, const void
   a.Kpad = k_pad; a.y_ld = d->y_ld; a.res_ld = d->res_ld;
   a.tiles_m = a.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
-  if (d->in_dtype == FSS_F32) return dispatch_conv<float, float>(a, s);
-  if (d->out_dtype == FSS_BF16) return dispatch_conv<bf16_t, bf16_t>(a, s);
-  return dispatch_conv<bf16_t, float>(a, s);
+  FSS_REQUIRE(d->config >= 0 && d->config <= kNumConvConfigs, "config out of range");
+  if (d->in_dtype == FSS_F32) return dispatch_conv<float, float>(a, d->config, s);
+  if (d->out_dtype == FSS_BF16) return dispatch_conv<bf16_t, bf16_t>(a, d->config, s);
+  return dispatch_conv<bf16_t, float>(a, d->config, s);
 }

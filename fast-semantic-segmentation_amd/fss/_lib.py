@@ -23,7 +23,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         'n', 'h', 'w', 'cin', 'cout', 'kh', 'kw', 'stride', 'dilation',
         'pad_top', 'pad_left', 'ho', 'wo', 'act', 'in_dtype', 'out_dtype',
-        'y_ld', 'res_ld', 'k_pad', 'cout_pad')]
+        'y_ld', 'res_ld', 'k_pad', 'cout_pad', 'config')]
 
 
 # name -> (restype, argtypes); must list every symbol of include/fss.h
@@ -52,6 +52,7 @@ PROTOTYPES = {
     'fss_graph_launch': (c_int, [c_void_p, c_void_p]),
     'fss_graph_destroy': (c_int, [c_void_p]),
     'fss_conv_pack_dims': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int_p, c_int_p]),
+    'fss_conv_config_count': (c_int, []),
     'fss_conv2d_nhwc': (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     'fss_dwconv2d_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14 + [c_void_p]),

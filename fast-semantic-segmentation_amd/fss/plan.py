@@ -87,7 +87,7 @@ class CompiledGraph(object):
     classifier stay float32)."""
 
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
-                 commute_classifier=True, use_hip_graph=True):
+                 commute_classifier=True, use_hip_graph=True, autotune=True):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
@@ -107,6 +107,8 @@ class CompiledGraph(object):
             self._import(graph, outputs, commute_classifier)
             self._lower()
             torch.cuda.synchronize(self.device)   # constants were uploaded on torch's stream
+            if autotune:
+                self._autotune_convs()
             self.run_eager()
             self.sync()
             if use_hip_graph:
@@ -554,6 +556,43 @@ class CompiledGraph(object):
         src = self._val(ln.inputs[0])
         self.vals[ln] = Val(src.buf, ln.shape, src.dt, phys_c=src.phys_c, ld=src.ld, coff=src.coff)
 
+    # ------------------------------------------------------------ conv tuning
+    _TUNE_CACHE = {}
+
+    def _autotune_convs(self, warm=2, reps=4):
+        """Times every tile configuration of the conv kernel on each distinct
+        layer shape (HIP events on the plan's stream) and keeps the fastest.
+        All configurations produce identical results, so this only affects speed."""
+        ncfg = lib.fss_conv_config_count()
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.call('fss_event_create', ctypes.byref(e0))
+        _lib.call('fss_event_create', ctypes.byref(e1))
+        ms = ctypes.c_float()
+        for s in self.steps:
+            if s.kind != 'conv':
+                continue
+            d = s.keep
+            key = tuple(getattr(d, f[0]) for f in d._fields_ if f[0] != 'config') + (s.args[4] is not None,)
+            best = self._TUNE_CACHE.get(key)
+            if best is None:
+                best, best_ms = 0, float('inf')
+                for cfg in range(1, ncfg + 1):
+                    d.config = cfg
+                    for _ in range(warm):
+                        check(s.fn(*s.args), s.name)
+                    _lib.call('fss_event_record', e0, self.sh)
+                    for _ in range(reps):
+                        check(s.fn(*s.args), s.name)
+                    _lib.call('fss_event_record', e1, self.sh)
+                    _lib.call('fss_event_sync', e1)
+                    _lib.call('fss_event_elapsed_ms', e0, e1, ctypes.byref(ms))
+                    if ms.value < best_ms:
+                        best, best_ms = cfg, ms.value
+                self._TUNE_CACHE[key] = best
+            d.config = best
+        _lib.call('fss_event_destroy', e0)
+        _lib.call('fss_event_destroy', e1)
+
     # -------------------------------------------------------------- execution
     def run_eager(self):
         for s in self.steps:
@@ -643,5 +682,6 @@ class CompiledGraph(object):
                 best[k] = min(best[k], ms.value)
         for e in evs:
             _lib.call('fss_event_destroy', e)
-        return [dict(kind=s.kind, name=s.name, ms=best[k], flops=s.flops, bytes=s.bytes)
+        return [dict(kind=s.kind, name=s.name, ms=best[k], flops=s.flops, bytes=s.bytes,
+                     config=(s.keep.config if s.kind == 'conv' else None))
                 for k, s in enumerate(self.steps)]

@@ -84,10 +84,14 @@ typedef struct fss_conv_desc {
   int32_t y_ld;              /* output pixel stride in elements (>= cout)  */
   int32_t res_ld;            /* residual pixel stride in elements          */
   int32_t k_pad, cout_pad;   /* packed weight dims                         */
+  int32_t config;            /* tile configuration: 0 = automatic, else
+                                1..fss_conv_config_count(); results do not
+                                depend on it, only speed does              */
 } fss_conv_desc;
 
 int fss_conv_pack_dims(int cin, int kh, int kw, int cout, int dtype,
                        int* k_pad, int* cout_pad);
+int fss_conv_config_count(void);
 
 /* y = act(conv(x, W) + bias [+ residual]).
  * Replaces slim.conv2d + slim.batch_norm(inference) + activation

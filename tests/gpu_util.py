@@ -43,7 +43,7 @@ def pack_conv_weights(w, dt, cin_phys=None):
 
 
 def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw=None,
-           act=None, dt='f32', out_dt=None, y_ld=None):
+           act=None, dt='f32', out_dt=None, y_ld=None, config=0):
     """x: [n,h,w,cin] float32 host array; returns float32 host array [n,ho,wo,cout]."""
     out_dt = out_dt or dt
     n, h, wd, cin = x.shape
@@ -58,7 +58,7 @@ def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw
     d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride,
                       dilation=rate, pad_top=pads[0], pad_left=pads[1], ho=ho, wo=wo,
                       act=_lib.ACT_CODES[act], in_dtype=DT[dt][0], out_dtype=DT[out_dt][0],
-                      y_ld=ld, res_ld=cout, k_pad=k_pad, cout_pad=cout_pad)
+                      y_ld=ld, res_ld=cout, k_pad=k_pad, cout_pad=cout_pad, config=config)
     torch.cuda.synchronize()
     _lib.call('fss_conv2d_nhwc', ctypes.byref(d), xd.data_ptr(), wdev.data_ptr(),
               bd.data_ptr() if bd is not None else None,

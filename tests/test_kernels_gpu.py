@@ -104,6 +104,26 @@ def test_conv2d_epilogue(dt, act):
     _close(got, ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'conv epilogue %s %s' % (dt, act))
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_conv2d_configs_agree_bitwise(dt):
+    """Every tile configuration accumulates each output over k in the same
+    order: results must be bit-identical, whatever the tuner picks."""
+    gu, L = _gu(), _lib()
+    rng = np.random.default_rng(11)
+    n, h, wd, cin, cout = 1, 37, 41, 64, 136
+    x = rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32)
+    w = rng.normal(0, 0.1, (3, 3, cin, cout)).astype(np.float32)
+    bias = rng.normal(0, 1, cout).astype(np.float32)
+    outs = []
+    for cfg in range(0, L.lib.fss_conv_config_count() + 1):
+        outs.append(gu.conv2d(x, w, bias, None, 1, 2, (2, 2), (h, wd), 'relu', dt, config=cfg))
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+    ref = O.relu(O.conv2d(gu.bf16_round(x) if dt == 'bf16' else x,
+                          gu.bf16_round(w) if dt == 'bf16' else w, 1, 2, 'SAME', np.float64) + bias)
+    _close(outs[0], ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'conv configs')
+
+
 def test_conv2d_rejects_bad_arguments():
     L = _lib()
     d = L.ConvDesc(n=1, h=8, w=8, cin=3, cout=8, kh=3, kw=3, stride=1, dilation=1, pad_top=1,
