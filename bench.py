@@ -71,7 +71,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=8, help='frames per step per GPU')
+    ap.add_argument('--batch', type=int, default=16, help='frames per step per GPU')
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-latency', action='store_true')
@@ -86,9 +86,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
+    # rehearsal knobs (several ranks on one GPU box): FSS_BENCH_BACKEND=gloo FSS_BENCH_DEVICE=0
+    backend = os.environ.get('FSS_BENCH_BACKEND', 'nccl')
+    if 'FSS_BENCH_DEVICE' in os.environ:
+        local_rank = int(os.environ['FSS_BENCH_DEVICE'])
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from fss import metrics
     B = args.batch
@@ -128,7 +135,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device='cuda' if backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     frames = world * B * args.steps

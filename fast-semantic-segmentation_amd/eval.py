@@ -1,0 +1,100 @@
+r"""mIoU evaluation of checkpoints (MI355X path).
+
+Same flags as the reference's eval.py:25-53 (--evaluate_all_from_checkpoint,
+--train_dir, --eval_dir, --config_path, --image_summaries, --verbose,
+--limit_gpu_mem) plus --dtype / --batch_size.  Launch one process per GPU with
+torch.distributed.run to shard the examples; the confusion matrix is all-reduced
+over RCCL.
+"""
+import argparse
+import functools
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def get_checkpoints_from_path(initial_checkpoint_path, checkpoint_dir):
+    from fss import checkpoint
+    state = checkpoint.get_checkpoint_state(checkpoint_dir)
+    if state is None:
+        raise ValueError('No checkpoints found in `train_dir`.')
+    all_checkpoints = state[1]
+    checkpoints_to_evaluate = None
+    for idx, ckpt in enumerate(all_checkpoints):
+        print(idx, ' ', str(ckpt))
+        full_init_ckpt_path = os.path.join(os.path.dirname(ckpt), initial_checkpoint_path)
+        if str(ckpt) == full_init_ckpt_path:
+            checkpoints_to_evaluate = all_checkpoints[idx:]
+            break
+    if checkpoints_to_evaluate is None:
+        raise ValueError('Checkpoint not found. Exiting.')
+    return checkpoints_to_evaluate
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--evaluate_all_from_checkpoint', default=None)
+    ap.add_argument('--train_dir', required=True)
+    ap.add_argument('--eval_dir', required=True)
+    ap.add_argument('--config_path', required=True)
+    ap.add_argument('--image_summaries', action='store_true')
+    ap.add_argument('--verbose', action='store_true')
+    ap.add_argument('--limit_gpu_mem', action='store_true')
+    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
+    ap.add_argument('--batch_size', type=int, default=1)
+    flags = ap.parse_args(argv)
+
+    import torch
+    import torch.distributed as dist
+    from google.protobuf import text_format
+    from builders import dataset_builder, model_builder
+    from protos import pipeline_pb2
+    from libs.evaluator import eval_segmentation_model, eval_segmentation_model_once
+
+    if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) > 1:
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        dist.init_process_group('nccl')
+    os.makedirs(flags.eval_dir, exist_ok=True)
+    if not os.path.isdir(flags.train_dir):
+        raise ValueError('`train_dir` must be a valid directory containing model checkpoints '
+                         'from training.')
+    pipeline_config = pipeline_pb2.PipelineConfig()
+    with open(flags.config_path) as f:
+        text_format.Merge(f.read(), pipeline_config)
+    eval_config = pipeline_config.eval_config
+    create_input_fn = functools.partial(dataset_builder.build,
+                                        input_reader_config=pipeline_config.eval_input_reader)
+    create_model_fn = functools.partial(model_builder.build, model_config=pipeline_config.model,
+                                        is_training=False)
+    input_type = eval_config.eval_input_type.WhichOneof('eval_input_type_oneof')
+    if input_type == 'cropped_eval_input':
+        c = eval_config.eval_input_type.cropped_eval_input
+        input_dims, cropped_evaluation = (c.height, c.width), True
+    elif input_type == 'padded_eval_input':
+        p = eval_config.eval_input_type.padded_eval_input
+        input_dims, cropped_evaluation = (p.height, p.width), False
+    else:
+        raise ValueError('Must specify an `eval_input_type` for evaluation.')
+    extra = dict(dtype=flags.dtype, batch_size=flags.batch_size)
+    if flags.evaluate_all_from_checkpoint is not None:
+        for curr_checkpoint in get_checkpoints_from_path(flags.evaluate_all_from_checkpoint,
+                                                         flags.train_dir):
+            result = eval_segmentation_model_once(
+                curr_checkpoint, create_model_fn, create_input_fn, input_dims, eval_config,
+                eval_dir=flags.eval_dir, cropped_evaluation=cropped_evaluation,
+                image_summaries=flags.image_summaries, verbose=flags.verbose, **extra)
+            print('Evaluation of `{}` over. Eval values: {}'.format(curr_checkpoint, result))
+    else:
+        result = eval_segmentation_model(
+            create_model_fn, create_input_fn, input_dims, eval_config, train_dir=flags.train_dir,
+            eval_dir=flags.eval_dir, cropped_evaluation=cropped_evaluation,
+            evaluate_single_checkpoint=flags.evaluate_all_from_checkpoint,
+            image_summaries=flags.image_summaries, verbose=flags.verbose, **extra)
+        print('Evaluation over. Eval values: {}'.format(result))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

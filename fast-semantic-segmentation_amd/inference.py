@@ -1,0 +1,97 @@
+r"""Run inference on an image or a directory of images (MI355X path).
+
+Same flags as the reference's inference.py:25-52:
+  --input_path --input_shape --pad_to_shape --config_path --trained_checkpoint
+  --output_dir --label_ids
+plus --dtype (bfloat16 | float32).
+"""
+import argparse
+import os
+import sys
+import timeit
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def _valid_file_ext(input_path):
+    return os.path.splitext(input_path)[-1].upper() in ['.JPG', '.JPEG', '.PNG']
+
+
+def _get_images_from_path(input_path):
+    image_file_paths = []
+    if os.path.isdir(input_path):
+        for dirpath, _, filenames in os.walk(input_path):
+            for f in sorted(filenames):
+                file_path = os.path.abspath(os.path.join(dirpath, f))
+                if _valid_file_ext(file_path):
+                    image_file_paths.append(file_path)
+        if len(image_file_paths) == 0:
+            raise ValueError('No images in directory. Files must be JPG or PNG')
+    else:
+        if not _valid_file_ext(input_path):
+            raise ValueError('File must be JPG or PNG.')
+        image_file_paths.append(input_path)
+    return image_file_paths
+
+
+def run_inference_graph(model, trained_checkpoint_prefix, input_images, input_shape, pad_to_shape,
+                        label_color_map, output_directory, dtype='bfloat16'):
+    from PIL import Image
+    from fss import checkpoint, graph as G
+    from libs.exporter import deploy_segmentation_inference_graph, Session
+    outputs, placeholder_tensor = deploy_segmentation_inference_graph(
+        model=model, input_shape=input_shape, pad_to_shape=pad_to_shape,
+        label_color_map=label_color_map)
+    weights = checkpoint.load_variables(trained_checkpoint_prefix, G.get_default_graph().variables)
+    sess = Session(outputs, placeholder_tensor, weights, dtype=dtype)
+    for idx, image_path in enumerate(input_images):
+        image_raw = np.array(Image.open(image_path))
+        start_time = timeit.default_timer()
+        predictions = sess.run(image_raw)
+        elapsed = timeit.default_timer() - start_time
+        print('{}) wall time: {}'.format(idx + 1, elapsed))
+        save_location = os.path.join(output_directory, os.path.basename(image_path))
+        predictions = predictions.astype(np.uint8)
+        if len(label_color_map[0]) == 1:
+            predictions = np.squeeze(predictions, -1)
+        Image.fromarray(predictions[0]).save(save_location, 'PNG')
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--input_path', required=True)
+    ap.add_argument('--input_shape', default='1024,2048,3')
+    ap.add_argument('--pad_to_shape', default='1025,2049')
+    ap.add_argument('--config_path', required=True)
+    ap.add_argument('--trained_checkpoint', required=True)
+    ap.add_argument('--output_dir', default='./')
+    ap.add_argument('--label_ids', action='store_true')
+    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
+    flags = ap.parse_args(argv)
+
+    from google.protobuf import text_format
+    from protos import pipeline_pb2
+    from builders import model_builder
+    from libs.constants import CITYSCAPES_LABEL_COLORS, CITYSCAPES_LABEL_IDS
+
+    os.makedirs(flags.output_dir, exist_ok=True)
+    pipeline_config = pipeline_pb2.PipelineConfig()
+    with open(flags.config_path) as f:
+        text_format.Merge(f.read(), pipeline_config)
+    if not flags.input_shape:
+        raise ValueError('Must supply `input_shape`')
+    input_shape = [int(d) if d != '-1' else None for d in flags.input_shape.split(',')]
+    pad_to_shape = None
+    if flags.pad_to_shape:
+        pad_to_shape = [int(d) if d != '-1' else None for d in flags.pad_to_shape.split(',')]
+    input_images = _get_images_from_path(flags.input_path)
+    label_map = CITYSCAPES_LABEL_IDS if flags.label_ids else CITYSCAPES_LABEL_COLORS
+    _, segmentation_model = model_builder.build(pipeline_config.model, is_training=False)
+    run_inference_graph(segmentation_model, flags.trained_checkpoint, input_images, input_shape,
+                        pad_to_shape, label_map, flags.output_dir, flags.dtype)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,113 @@
+"""Checkpoint-V2 and TFRecord readers: round trips against the writers in this
+repo and known answers of the primitives (crc32c, varint, block layout).
+
+Format parity is UNPINNED against TensorFlow-written files: none ship with the
+reference (the Model Zoo is a set of remote links, docs/model_zoo.md:5-12) and
+TensorFlow is not installed, so only self-consistency and the published
+primitives' test vectors are checked here.
+"""
+import io
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from fss import checkpoint, tfrecord
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 appendix B.4 test vectors
+    assert checkpoint.crc32c(b'\x00' * 32) == 0x8A9136AA
+    assert checkpoint.crc32c(b'\xff' * 32) == 0x62A8AB43
+    assert checkpoint.crc32c(bytes(range(32))) == 0x46DD794E
+    assert checkpoint.crc32c(b'123456789') == 0xE3069283
+    # LevelDB mask: rotate right 15, add constant
+    c = checkpoint.crc32c(b'foo')
+    assert checkpoint.masked_crc32c(b'foo') == ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xa282ead8) & 0xFFFFFFFF
+
+
+def test_checkpoint_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    variables = {}
+    for i in range(300):            # enough entries for several index blocks + prefix sharing
+        name = 'SharedFeatureExtractor/resnet_v1_50/block%d/unit_%d/bottleneck_v1/conv%d/weights' % (
+            i % 4 + 1, i // 12 + 1, i % 3 + 1)
+        variables[name + '_%d' % i] = rng.normal(size=(1, 1, i % 7 + 1, 3)).astype(np.float32)
+    variables['global_step'] = np.asarray(1234, np.int64)
+    variables['Predictions/Conv/biases'] = rng.normal(size=(19,)).astype(np.float32)
+    variables['big'] = rng.normal(size=(300, 300)).astype(np.float32)      # > 64 KiB
+    prefix = str(tmp_path / 'model.ckpt-7')
+    checkpoint.save_variables(prefix, variables)
+    assert os.path.exists(prefix + '.index') and os.path.exists(prefix + '.data-00000-of-00001')
+    with open(prefix + '.index', 'rb') as f:
+        assert struct.unpack('<Q', f.read()[-8:])[0] == 0xdb4775248b80fb57
+    got = checkpoint.load_variables(prefix)
+    assert set(got) == set(variables)
+    for k, v in variables.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape
+        np.testing.assert_array_equal(got[k], v)
+    # subset load tolerates extra variables, checks shapes, reports missing ones
+    sub = checkpoint.load_variables(prefix, {'Predictions/Conv/biases': (19,)})
+    assert list(sub) == ['Predictions/Conv/biases']
+    with pytest.raises(KeyError, match='missing 1 variables'):
+        checkpoint.load_variables(prefix, ['nope/weights'])
+    with pytest.raises(ValueError, match='expected'):
+        checkpoint.load_variables(prefix, {'Predictions/Conv/biases': (20,)})
+    # corruption is detected
+    raw = bytearray(open(prefix + '.index', 'rb').read())
+    raw[10] ^= 0xFF
+    open(prefix + '.index', 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='checksum'):
+        checkpoint.load_variables(prefix)
+
+
+def test_checkpoint_state_file(tmp_path):
+    d = str(tmp_path)
+    assert checkpoint.latest_checkpoint(d) is None
+    checkpoint.write_checkpoint_state(d, [os.path.join(d, 'model.ckpt-1'), os.path.join(d, 'model.ckpt-2')])
+    latest, allp = checkpoint.get_checkpoint_state(d)
+    assert latest == os.path.join(d, 'model.ckpt-2')
+    assert allp == [os.path.join(d, 'model.ckpt-1'), os.path.join(d, 'model.ckpt-2')]
+    import eval as eval_cli
+    assert eval_cli.get_checkpoints_from_path('model.ckpt-2', d) == [os.path.join(d, 'model.ckpt-2')]
+    with pytest.raises(ValueError, match='Checkpoint not found'):
+        eval_cli.get_checkpoints_from_path('model.ckpt-9', d)
+
+
+def test_tfrecord_example_round_trip(tmp_path):
+    from PIL import Image
+    from builders import dataset_builder
+    from protos import input_reader_pb2
+    rng = np.random.default_rng(1)
+    records, expected = [], []
+    for i in range(3):
+        img = rng.integers(0, 256, (12, 16, 3)).astype(np.uint8)
+        lab = rng.integers(0, 19, (12, 16)).astype(np.uint8)
+        lab[0, 0] = 255
+        bi, bl = io.BytesIO(), io.BytesIO()
+        Image.fromarray(img).save(bi, 'PNG')
+        Image.fromarray(lab).save(bl, 'PNG')
+        records.append(tfrecord.make_example({
+            'image/encoded': bi.getvalue(), 'image/filename': b'x.png', 'image/format': b'png',
+            'image/height': 12, 'image/width': 16, 'image/channels': 3,
+            'image/segmentation/class/encoded': bl.getvalue(),
+            'image/segmentation/class/format': b'png'}))
+        expected.append((img, lab))
+    path = str(tmp_path / 'val.record')
+    tfrecord.write_records(path, records)
+    ex = tfrecord.parse_example(next(tfrecord.read_records(path, verify=True)))
+    assert ex['image/height'] == [12] and ex['image/format'] == [b'png']
+    cfg = input_reader_pb2.InputReader()
+    cfg.shuffle = False
+    cfg.tf_record_input_reader.input_path.append(path)
+    got = list(dataset_builder.build(cfg))
+    assert len(got) == 3
+    for (gi, gl), (ei, el) in zip(got, expected):
+        np.testing.assert_array_equal(gi, ei)
+        np.testing.assert_array_equal(gl, el)
+    with pytest.raises(ValueError, match='At least one input path'):
+        cfg2 = input_reader_pb2.InputReader()
+        dataset_builder.build(cfg2)
+    with pytest.raises(ValueError, match='not of type'):
+        dataset_builder.build(object())

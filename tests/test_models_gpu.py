@@ -139,3 +139,95 @@ def test_inference_session_matches_oracle():
                                      (257, 513), table)
         assert got.shape == ref.shape == (1, 256, 512, len(table[0])) and got.dtype == np.float32
         assert (np.all(got == ref, axis=-1)).mean() >= 0.999
+
+
+def _eval_examples(n, h, w, seed=5):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        img = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+        lab = rng.integers(0, 19, (h, w)).astype(np.uint8)
+        lab[rng.random((h, w)) < 0.05] = 255
+        out.append((img, lab))
+    return out
+
+
+@pytest.mark.parametrize('batch_size', [1, 2])
+def test_evaluator_confusion_matrix_and_miou_bit_exact(batch_size):
+    """libs.evaluator surface: mIoU over padded examples.  Given the GPU's own
+    label maps, the confusion matrix and mIoU must equal the oracle's exactly;
+    zero-padded label pixels count as class 0; a ragged last batch is handled."""
+    import functools
+    from google.protobuf import text_format
+    from protos import pipeline_pb2
+    from builders import model_builder
+    from fss import graph as G, synth, plan
+    from libs import evaluator
+    cfg = pipeline_pb2.PipelineConfig()
+    text_format.Merge(CFG % dict(arch='icnet', ext='dilated_resnet50', fs=0.5,
+                                 pf=[1.0, 2.0, 3.0, 4.0], h=257, w=513), cfg)
+    cfg.eval_config.num_examples = 5
+    examples = _eval_examples(7, 256, 512)          # only the first 5 may be used
+    create_model_fn = functools.partial(model_builder.build, model_config=cfg.model, is_training=False)
+    g = G.reset_default_graph()
+    model_builder.build(cfg.model, is_training=False)[1].predict(
+        G.channel_affine(G.to_float(G.placeholder((1, 257, 513, 3))), [0, 0, 0], [1, 1, 1]))
+    weights = synth.make_weights(g.variables)
+    miou, cm = evaluator.eval_segmentation_model(
+        create_model_fn, lambda: iter(examples), (257, 513), cfg.eval_config, train_dir=None,
+        eval_dir=None, weights=weights, dtype='float32', batch_size=batch_size,
+        return_confusion=True)
+    # independent pass: label maps from a plain batch-1 plan, metric from the oracle
+    g = G.reset_default_graph()
+    _, model = model_builder.build(cfg.model, is_training=False)
+    preds, ph = evaluator.create_predictions_and_labels(model, (256, 512, 3), 257, 513, False, 1)
+    cg = plan.CompiledGraph(g, [preds], weights, dtype='float32')
+    ref_cm = np.zeros((19, 19), np.int64)
+    for img, lab in examples[:5]:
+        labels = cg.run(img)[0][0, :, :, 0]
+        padded = np.zeros((257, 513), np.uint8)
+        padded[:256, :512] = lab
+        ref_cm += OM.confusion_matrix(labels, padded, 19, 255)
+    assert np.array_equal(cm, ref_cm)
+    assert miou == OM.mean_iou(ref_cm)
+    assert cm[0].sum() > 257 + 513 - 1 - 1        # the padded row / column landed in class 0
+
+
+def test_cli_inference_from_checkpoint(tmp_path):
+    """inference.py surface: config file + checkpoint prefix + PNG in, PNG out."""
+    from PIL import Image
+    from fss import checkpoint, graph as G, synth
+    from google.protobuf import text_format
+    from protos import pipeline_pb2
+    from builders import model_builder
+    from libs.constants import CITYSCAPES_LABEL_IDS
+    import inference
+    cfg_text = CFG % dict(arch='icnet', ext='dilated_resnet50', fs=0.5, pf=[1.0, 2.0, 3.0, 4.0],
+                          h=257, w=513)
+    cfg_path = tmp_path / 'model.config'
+    cfg_path.write_text(cfg_text)
+    cfg = pipeline_pb2.PipelineConfig()
+    text_format.Merge(cfg_text, cfg)
+    g = G.reset_default_graph()
+    _, model = model_builder.build(cfg.model, is_training=False)
+    model.predict(model.preprocess(G.to_float(G.placeholder((1, 257, 513, 3)))))
+    weights = synth.make_weights(g.variables)
+    extra = dict(weights)
+    extra['global_step'] = np.asarray(7, np.int64)                  # ignored by the loader
+    extra['AuxOutput/weights'] = np.zeros((1, 1, 128, 19), np.float32)
+    prefix = str(tmp_path / 'train' / 'model.ckpt-7')
+    checkpoint.save_variables(prefix, extra)
+    img = np.random.default_rng(3).integers(0, 256, (256, 512, 3)).astype(np.uint8)
+    (tmp_path / 'in').mkdir()
+    Image.fromarray(img).save(str(tmp_path / 'in' / 'frame.png'))
+    G.reset_default_graph()
+    inference.main(['--input_path', str(tmp_path / 'in'), '--input_shape', '256,512,3',
+                    '--pad_to_shape', '257,513', '--config_path', str(cfg_path),
+                    '--trained_checkpoint', prefix, '--output_dir', str(tmp_path / 'out'),
+                    '--label_ids', '--dtype', 'float32'])
+    got = np.asarray(Image.open(str(tmp_path / 'out' / 'frame.png')))
+    P = nets.Params(weights)
+    ref = nets.inference_outputs(lambda x: nets.icnet_predict(P, x, filter_scale=2.0), img,
+                                 (256, 512, 3), (257, 513), CITYSCAPES_LABEL_IDS)
+    assert got.shape == (256, 512) and got.dtype == np.uint8
+    assert (got == ref[0, :, :, 0].astype(np.uint8)).mean() >= 0.999
