@@ -30,6 +30,24 @@ PAD_SHAPE = (1025, 2049)
 PEAK_TFLOPS = {'bfloat16': 2500.0, 'float32': 157.3}
 
 
+def measured_conv_traffic(batch, n_conv, dtype):
+    """HBM bytes per conv launch from the committed PMC passes (TCC FETCH_SIZE /
+    WRITE_SIZE collected by rocprofv3 in separate runs of this script, with the
+    gfx950 fetch correction already applied); None when no measurement of this
+    dtype is on disk.  Counters cannot be read from inside the process."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*conv_traffic*.json'))):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get('dtype', 'bfloat16') == dtype:
+            best = d
+    if best is None:
+        return None
+    per_frame = best['conv_hbm_bytes_per_step'] / best['frames_per_step']
+    return per_frame * batch / n_conv
+
+
 def build_plan(batch, dtype, with_labels=True):
     from google.protobuf import text_format
     from protos import pipeline_pb2
@@ -172,7 +190,9 @@ def main():
                        'parallelism': 'frames sharded over %d GPU(s)' % world},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': None,
+                         'frac': achieved / peak,
+                         'traffic': measured_conv_traffic(B, n_conv, args.dtype),
+                         'algorithmic_bytes': sum(p['bytes'] for p in prof if p['kind'] == 'conv') / n_conv,
                          'launches_per_step': n_conv,
                          'avg_launch_ms': conv_ms / n_conv,
                          'algorithmic_gflop_per_frame': conv_flops / B / 1e9},
