@@ -49,19 +49,54 @@ struct ConvArgs {
   int M, K, Kpad, y_ld, res_ld, tiles_m, tiles_n;
 };
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// MFMA shapes.  FM = edge of the square output tile of one instruction.
+//   FM = 32: lane (r = lane&31, g = lane>>5) supplies row r, 16 bytes of k-group g (2 groups);
+//            accumulator reg q holds C[(q&3) + 8*(q>>2) + 4*g][r].
+//   FM = 16: lane (r = lane&15, g = lane>>4) supplies row r, 16 bytes of k-group g (4 groups);
+//            accumulator reg q holds C[4*g + q][r].
+// A float chunk is 4 k values, consumed by 4 f32 MFMAs with the same k permutation
+// on both operands.
+template <typename T, int FM> struct Mma;
+template <> struct Mma<bf16_t, 32> {
+  typedef f32x16 acc_t;
+  static constexpr int NREG = 16;
+  static __device__ __forceinline__ int row_of(int q, int g) { return (q & 3) + 8 * (q >> 2) + 4 * g; }
+  static __device__ __forceinline__ void run(acc_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                   __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
   }
 };
-template <> struct Mma<float> {
-  static __device__ __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
+template <> struct Mma<bf16_t, 16> {
+  typedef f32x4 acc_t;
+  static constexpr int NREG = 4;
+  static __device__ __forceinline__ int row_of(int q, int g) { return 4 * g + q; }
+  static __device__ __forceinline__ void run(acc_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                  __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float, 32> {
+  typedef f32x16 acc_t;
+  static constexpr int NREG = 16;
+  static __device__ __forceinline__ int row_of(int q, int g) { return (q & 3) + 8 * (q >> 2) + 4 * g; }
+  static __device__ __forceinline__ void run(acc_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float, 16> {
+  typedef f32x4 acc_t;
+  static constexpr int NREG = 4;
+  static __device__ __forceinline__ int row_of(int q, int g) { return 4 * g + q; }
+  static __device__ __forceinline__ void run(acc_t& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
   }
 };
 
@@ -87,9 +122,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // ALIGNED: cin is a multiple of the K tile, so a tile never straddles two filter
 // taps and the tap walk is wave-uniform (scalar) instead of per lane.
 template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE,
-          bool ALIGNED>
+          int FM, bool ALIGNED>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
 conv_igemm_kernel(const ConvArgs a) {
+  typedef Mma<T, FM> MMA;
+  constexpr int LG = 64 / FM;               // lane groups = 16-byte k-groups per MFMA step
+  constexpr int KSTEPS = BKB / (16 * LG);   // MFMA steps per K tile
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int CPR = BKB / 16;             // chunks per tile row (4 or 8)
@@ -99,7 +137,7 @@ conv_igemm_kernel(const ConvArgs a) {
   constexpr int LOADS = A_IT + B_IT;        // DMA pieces per wave per stage
   constexpr int RSTEP = NT / CPR;           // row step between a thread's chunks
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
-  constexpr int MI = WTM / 32, NI = WTN / 32;
+  constexpr int MI = WTM / FM, NI = WTN / FM;
   constexpr int STAGE_BYTES = (BM + BN) * BKB;
   constexpr int SWZ_SHIFT = CPR == 4 ? 2 : 1;   // rows that share a bank window
   static_assert(CPR == 4 || CPR == 8, "BKB must be 64 or 128");
@@ -227,20 +265,20 @@ conv_igemm_kernel(const ConvArgs a) {
   };
 
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int swz = (l31 >> SWZ_SHIFT) & (CPR - 1);
+  const int lrow = lane & (FM - 1), lg = lane / FM;
+  const int swz = (lrow >> SWZ_SHIFT) & (CPR - 1);
   // byte offset, inside a row, of the fragment this lane reads at k step s
-  int frag_off[BKB / 32];
+  int frag_off[KSTEPS];
 #pragma unroll
-  for (int s = 0; s < BKB / 32; ++s) frag_off[s] = ((2 * s + lh) ^ swz) * 16;
+  for (int s = 0; s < KSTEPS; ++s) frag_off[s] = ((LG * s + lg) ^ swz) * 16;
 
-  f32x16 acc[MI][NI];
+  typename MMA::acc_t acc[MI][NI];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < MMA::NREG; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
@@ -250,21 +288,21 @@ conv_igemm_kernel(const ConvArgs a) {
     wait_vmcnt<(NSTAGE - 2) * LOADS>();      // this wave's pieces of tile kt have landed
     __builtin_amdgcn_s_barrier();            // ... and everybody else's; slot `fill` is free
     issue(kt + NSTAGE - 1, fill);
-    const char* pa = smem + slot * STAGE_BYTES + (wm * WTM + l31) * BKB;
-    const char* pb = smem + slot * STAGE_BYTES + BM * BKB + (wn * WTN + l31) * BKB;
+    const char* pa = smem + slot * STAGE_BYTES + (wm * WTM + lrow) * BKB;
+    const char* pb = smem + slot * STAGE_BYTES + BM * BKB + (wn * WTN + lrow) * BKB;
 #pragma unroll
-    for (int s = 0; s < BKB / 32; ++s) {
+    for (int s = 0; s < KSTEPS; ++s) {
       uint4 fa[MI], fb[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
-        fa[i] = *reinterpret_cast<const uint4*>(pa + i * 32 * BKB + frag_off[s]);
+        fa[i] = *reinterpret_cast<const uint4*>(pa + i * FM * BKB + frag_off[s]);
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        fb[j] = *reinterpret_cast<const uint4*>(pb + j * 32 * BKB + frag_off[s]);
+        fb[j] = *reinterpret_cast<const uint4*>(pb + j * FM * BKB + frag_off[s]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) Mma<T>::run(acc[i][j], fa[i], fb[j]);
+        for (int j = 0; j < NI; ++j) MMA::run(acc[i][j], fa[i], fb[j]);
     }
     slot = slot + 1 == NSTAGE ? 0 : slot + 1;
     fill = fill + 1 == NSTAGE ? 0 : fill + 1;
@@ -272,9 +310,8 @@ conv_igemm_kernel(const ConvArgs a) {
   wait_vmcnt<0>();                           // drain the zero-fill tail pieces
   __syncthreads();                           // everyone is done with the ring
 
-  // ---- epilogue: per wave, 32 rows at a time through LDS.
-  // Accumulator register r of lane l holds
-  //   C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] of its 32x32 tile.
+  // ---- epilogue: per wave, 32 rows at a time through LDS (MMA::row_of maps an
+  // accumulator register to its row inside the FM x FM tile; the column is lrow).
   constexpr int SROW = WTN + 4;              // staging row stride in floats
   static_assert(WAVES_M * WAVES_N * 32 * SROW * 4 <= NSTAGE * STAGE_BYTES,
                 "epilogue staging does not fit in the ring");
@@ -291,18 +328,21 @@ conv_igemm_kernel(const ConvArgs a) {
                       ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
                       (rg == nullptr ||
                        (((a.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.res) & 15) == 0)));
+  constexpr int TPS = 32 / FM;               // MFMA tile rows per 32-row slab
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
+  for (int sl = 0; sl < WTM / 32; ++sl) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int n = n_base + j * 32 + l31;
+      const int n = n_base + j * FM + lrow;
       const float bias = (a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[((r & 3) + 8 * (r >> 2) + 4 * lh) * SROW + j * 32 + l31] = acc[i][j][r] + bias;
+      for (int ti = 0; ti < TPS; ++ti)
+#pragma unroll
+        for (int r = 0; r < MMA::NREG; ++r)
+          stage[(ti * FM + MMA::row_of(r, lg)) * SROW + j * FM + lrow] = acc[sl * TPS + ti][j][r] + bias;
     }
     __syncthreads();
-    const int m_base = tile_m * BM + wm * WTM + i * 32;
+    const int m_base = tile_m * BM + wm * WTM + sl * 32;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int g = lane + p * 64;
@@ -351,7 +391,7 @@ conv_igemm_kernel(const ConvArgs a) {
 }
 
 template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE,
-          bool ALIGNED>
+          int FM, bool ALIGNED>
 static int launch_conv_impl(ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BKB;
@@ -362,7 +402,7 @@ static int launch_conv_impl(ConvArgs& a, hipStream_t stream) {
     set_error("fss_conv2d_nhwc: grid out of range");
     return 2;
   }
-  auto kern = conv_igemm_kernel<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, ALIGNED>;
+  auto kern = conv_igemm_kernel<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, FM, ALIGNED>;
   if (smem > 64 * 1024) {
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -384,34 +424,50 @@ static int launch_conv_impl(ConvArgs& a, hipStream_t stream) {
   return 0;
 }
 
-template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE>
+template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE, int FM>
 static int launch_conv(ConvArgs& a, hipStream_t stream) {
   constexpr int BK = BKB / (int)sizeof(T);
   if (a.Cin % BK == 0 && a.KH * a.KW <= 63)
-    return launch_conv_impl<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, true>(a, stream);
-  return launch_conv_impl<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, false>(a, stream);
+    return launch_conv_impl<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, FM, true>(a, stream);
+  return launch_conv_impl<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, FM, false>(a, stream);
 }
 
 // Tile configurations.  Every configuration is legal for every layer (tiles
-// larger than the problem only waste lanes) and all of them accumulate each
-// output element over k in the same order, so results do not depend on the
-// choice; which one is fastest depends on M, N, K and is best measured
-// (fss.plan times the candidates once per distinct layer shape).
-//   columns: BM, BN, waves M x N, bytes of K per tile row, ring stages
-#define FSS_CONV_CONFIGS(X)   \
-  X(1, 128, 128, 2, 2, 64, 4)  \
-  X(2, 128, 128, 2, 2, 64, 3)  \
-  X(3, 128, 128, 2, 2, 128, 2) \
-  X(4, 256, 128, 4, 2, 128, 2) \
-  X(5, 128, 64, 2, 2, 128, 2)  \
-  X(6, 128, 64, 2, 2, 64, 4)   \
-  X(7, 128, 64, 2, 2, 64, 3)   \
-  X(8, 128, 64, 2, 2, 64, 2)   \
-  X(9, 64, 64, 2, 2, 128, 2)   \
-  X(10, 64, 64, 2, 2, 64, 4)   \
-  X(11, 128, 32, 2, 1, 64, 4)  \
-  X(12, 128, 32, 2, 1, 64, 2)
-static constexpr int kNumConvConfigs = 12;
+// larger than the problem only waste lanes).  Configurations with the same MFMA
+// shape accumulate each output element over k in the same order, so their results
+// are bit-identical; the two shapes differ in the last float bits.  Which one is
+// fastest depends on M, N, K and is best measured (fss.plan times the candidates
+// once per distinct layer shape).  The 16x16 shape does the same FLOP per cycle as
+// the 32x32 one; the chip holds a higher clock on it under sustained load.
+//   columns: BM, BN, waves M x N, bytes of K per tile row, ring stages, MFMA tile edge
+#define FSS_CONV_CONFIGS(X)        \
+  X(1, 128, 128, 2, 2, 64, 4, 32)   \
+  X(2, 128, 128, 2, 2, 64, 3, 32)   \
+  X(3, 128, 128, 2, 2, 128, 2, 32)  \
+  X(4, 256, 128, 4, 2, 128, 2, 32)  \
+  X(5, 128, 64, 2, 2, 128, 2, 32)   \
+  X(6, 128, 64, 2, 2, 64, 4, 32)    \
+  X(7, 128, 64, 2, 2, 64, 3, 32)    \
+  X(8, 128, 64, 2, 2, 64, 2, 32)    \
+  X(9, 64, 64, 2, 2, 128, 2, 32)    \
+  X(10, 64, 64, 2, 2, 64, 4, 32)    \
+  X(11, 128, 32, 2, 1, 64, 4, 32)   \
+  X(12, 128, 32, 2, 1, 64, 2, 32)   \
+  X(13, 256, 128, 4, 2, 64, 3, 32)  \
+  X(14, 128, 128, 2, 2, 64, 4, 16)  \
+  X(15, 128, 128, 2, 2, 64, 3, 16)  \
+  X(16, 128, 128, 2, 2, 128, 2, 16) \
+  X(17, 256, 128, 4, 2, 128, 2, 16) \
+  X(18, 128, 64, 2, 2, 128, 2, 16)  \
+  X(19, 128, 64, 2, 2, 64, 4, 16)   \
+  X(20, 128, 64, 2, 2, 64, 3, 16)   \
+  X(21, 128, 64, 2, 2, 64, 2, 16)   \
+  X(22, 64, 64, 2, 2, 128, 2, 16)   \
+  X(23, 64, 64, 2, 2, 64, 4, 16)    \
+  X(24, 128, 32, 2, 1, 64, 4, 16)   \
+  X(25, 128, 32, 2, 1, 64, 2, 16)   \
+  X(26, 256, 128, 4, 2, 64, 3, 16)
+static constexpr int kNumConvConfigs = 26;
 
 // automatic choice when the caller does not name a configuration
 static int default_config(const ConvArgs& a) {
@@ -428,8 +484,8 @@ template <typename T, typename TO>
 static int dispatch_conv(ConvArgs& a, int config, hipStream_t stream) {
   if (config == 0) config = default_config(a);
   switch (config) {
-#define FSS_CASE(ID, BM, BN, WM, WN, BKB, NS) \
-  case ID: return launch_conv<T, TO, BM, BN, WM, WN, BKB, NS>(a, stream);
+#define FSS_CASE(ID, BM, BN, WM, WN, BKB, NS, FM) \
+  case ID: return launch_conv<T, TO, BM, BN, WM, WN, BKB, NS, FM>(a, stream);
     FSS_CONV_CONFIGS(FSS_CASE)
 #undef FSS_CASE
     default: break;
@@ -454,6 +510,23 @@ extern "C" int fss_conv_pack_dims(int cin, int kh, int kw, int cout, int dtype, 
 }
 
 extern "C" int fss_conv_config_count(void) { return kNumConvConfigs; }
+
+extern "C" int fss_conv_config_info(int config, int info[7]) {
+  FSS_REQUIRE(info != nullptr, "null argument");
+  switch (config) {
+#define FSS_INFO(ID, BM, BN, WM, WN, BKB, NS, FM)                                  \
+  case ID: {                                                                       \
+    const int v[7] = {BM, BN, WM, WN, BKB, NS, FM};                                \
+    for (int i = 0; i < 7; ++i) info[i] = v[i];                                    \
+    return 0;                                                                      \
+  }
+    FSS_CONV_CONFIGS(FSS_INFO)
+#undef FSS_INFO
+    default: break;
+  }
+  set_error("fss_conv_config_info: config out of range");
+  return 2;
+}
 
 extern "C" int fss_conv2d_nhwc(const fss_conv_desc* d, const void* x, const void* w_packed,
                                const float* bias, const void* residual, void* y, void* stream) {

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'libfss_gfx950.so')
+# FSS_LIB: another build of the same library (kernel experiments)
+LIB_PATH = os.environ.get('FSS_LIB') or os.path.join(os.path.dirname(_HERE), 'libfss_gfx950.so')
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
@@ -53,8 +54,11 @@ PROTOTYPES = {
     'fss_graph_destroy': (c_int, [c_void_p]),
     'fss_conv_pack_dims': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int_p, c_int_p]),
     'fss_conv_config_count': (c_int, []),
+    'fss_conv_config_info': (c_int, [c_int, c_int_p]),
     'fss_conv2d_nhwc': (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    'fss_stem_pack_dims': (c_int, [c_int, c_int, c_int, c_int, c_int_p, c_int_p]),
+    'fss_stem_conv_u8': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float_p, c_float_p] + [c_int] * 12 + [c_void_p]),
     'fss_dwconv2d_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14 + [c_void_p]),
     'fss_maxpool_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     'fss_subsample_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),

@@ -7,6 +7,8 @@ sequence into a hipGraph that `launch()` replays.
 
 Fusions (each replaces a chain of reference ops by one kernel):
   * placeholder -> pad_to_bounding_box -> to_float -> channel affine   => fss_preprocess_u8
+  * ... that chain [-> exact 1/f align_corners resize] -> first conv2d + batch norm
+    + activation                                                       => fss_stem_conv_u8
   * conv2d + folded batch norm + activation [+ add(other) [+ relu]]    => fss_conv2d_nhwc
   * x + resize(avg_pool(x)) + ... of the fast pyramid pooling module   => fss_pyramid_add_nhwc
   * resize(logits) -> argmax                                           => fss_upsample_argmax
@@ -20,6 +22,8 @@ Device memory, streams and host<->device copies go through torch; all
 arithmetic goes through libfss_gfx950.so.
 """
 import ctypes
+import json
+import os
 
 import numpy as np
 import torch
@@ -87,7 +91,8 @@ class CompiledGraph(object):
     classifier stay float32)."""
 
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
-                 commute_classifier=True, use_hip_graph=True, autotune=True):
+                 commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
+                 fuse_stem=True):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
@@ -103,6 +108,12 @@ class CompiledGraph(object):
         self.input_val = None
         self.graph_exec = None
         self.param_bytes = 0
+        # MFMA shape class of the conv kernel: 16 (v_mfma_*_16x16*) or 32 (v_mfma_*_32x32*)
+        self.mfma_edge = int(mfma_edge or os.environ.get('FSS_MFMA_EDGE', 16 if self.dt == 'bf16' else 32))
+        if self.mfma_edge not in (16, 32):
+            raise ValueError('mfma_edge must be 16 or 32')
+        self.fuse_stem = fuse_stem
+        self.tuned_now = 0      # layer shapes timed by this plan (0: all came from the table)
         with torch.cuda.device(self.device):
             self._import(graph, outputs, commute_classifier)
             self._lower()
@@ -254,17 +265,22 @@ class CompiledGraph(object):
         src = self.image_src.get(ln.inputs[0])
         if src is None:
             raise NotImplementedError('channel_affine is only supported on the input image')
-        n, ho, wo, c = ln.shape
-        pc = _EPC[self.dt]
-        out = Val(self._alloc(ln.shape, self.dt, phys_c=pc), ln.shape, self.dt, phys_c=pc)
-        self.vals[ln] = out
-        x = self.vals[src]
-        _, h, w, _ = x.shape
-        mean = (ctypes.c_float * 3)(*ln.attrs['mean'])
-        scale = (ctypes.c_float * 3)(*ln.attrs['scale'])
-        self._emit('preprocess', 'preprocess', 'fss_preprocess_u8',
-                   (x.ptr, out.ptr, n, h, w, ho, wo, pc, mean, scale, _CODE[self.dt], self.sh),
-                   nbytes=n * h * w * 3 + n * ho * wo * pc * _ESZ[self.dt], keep=(mean, scale))
+
+        def materialise():
+            n, ho, wo, c = ln.shape
+            pc = _EPC[self.dt]
+            out = Val(self._alloc(ln.shape, self.dt, phys_c=pc), ln.shape, self.dt, phys_c=pc)
+            self.vals[ln] = out
+            x = self.vals[src]
+            _, h, w, _ = x.shape
+            mean = (ctypes.c_float * 3)(*ln.attrs['mean'])
+            scale = (ctypes.c_float * 3)(*ln.attrs['scale'])
+            self._emit('preprocess', 'preprocess', 'fss_preprocess_u8',
+                       (x.ptr, out.ptr, n, h, w, ho, wo, pc, mean, scale, _CODE[self.dt], self.sh),
+                       nbytes=n * h * w * 3 + n * ho * wo * pc * _ESZ[self.dt], keep=(mean, scale))
+
+        # deferred: a first convolution reads the uint8 frame itself (see _stem_source)
+        self.lazy[ln] = ('preprocess', src, materialise)
 
     # ---- convolutions
     def _fold_bn(self, a, cout):
@@ -280,8 +296,69 @@ class CompiledGraph(object):
             return scale, bias
         return np.ones(cout, np.float64), W[a['biases']].astype(np.float64)
 
+    def _stem_source(self, ln):
+        """(preprocess node, sampling step, logical h, w) when conv `ln` can run as
+        fss_stem_conv_u8: its input is the still-unmaterialised preprocessed frame, or
+        an align_corners shrink of it by an exact integer factor (pure subsampling)."""
+        a = ln.attrs
+        inp, sub = ln.inputs[0], 1
+        if not self.fuse_stem or inp in self.vals:
+            return None
+        d = self.lazy.get(inp)
+        if d and d[0] == 'resize' and d[2]:
+            small, big = inp.shape, d[1].shape
+            if small[1] < 2 or small[2] < 2 or d[1] in self.vals:
+                return None
+            f = (big[1] - 1) // (small[1] - 1)
+            if not (2 <= f <= 8 and (big[1] - 1) == f * (small[1] - 1) and (big[2] - 1) == f * (small[2] - 1)):
+                return None
+            inp, sub = d[1], f
+            d = self.lazy.get(inp)
+        if not d or d[0] != 'preprocess':
+            return None
+        if not (a['biases'] is None and ln.shape[3] <= 64 and a['kh'] * a['kw'] <= 64
+                and a['stride'] <= 4 and a['rate'] <= 4 and self._only_consumer(ln, 'add') is None):
+            return None
+        return inp, sub, ln.inputs[0].shape[1], ln.inputs[0].shape[2]
+
+    def _l_stem_conv(self, ln, pre, sub, h, w):
+        a = ln.attrs
+        x = self.vals[self.lazy[pre][1]]                      # the uint8 frames
+        n, hr, wr, _ = x.shape
+        _, ho, wo, cout = ln.shape
+        kh, kw = a['kh'], a['kw']
+        scale, bias = self._fold_bn(a, cout)
+        Wt = self.weights[a['weights']].astype(np.float64) * scale      # [kh,kw,3,cout]
+        Wt = np.pad(Wt, ((0, 0), (0, 0), (0, 1), (0, 0)))
+        k_pad, cout_pad = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.call('fss_stem_pack_dims', kh, kw, cout, _CODE[self.dt], ctypes.byref(k_pad),
+                  ctypes.byref(cout_pad))
+        Wp = np.zeros((cout_pad.value, k_pad.value), np.float32)
+        Wp[:cout, :kh * kw * 4] = Wt.transpose(3, 0, 1, 2).reshape(cout, -1)
+        if self.dt == 'bf16':
+            wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+        else:
+            wdev = torch.from_numpy(Wp).to(self.device)
+        self.keepalive.append(wdev)
+        bdev = self._dev_f32(bias)
+        self.param_bytes += cout * kh * kw * 3 * _ESZ[self.dt]
+        out = Val(self._alloc(ln.shape, self.dt), ln.shape, self.dt)
+        self.vals[ln] = out
+        mean = (ctypes.c_float * 3)(*pre.attrs['mean'])
+        sc = (ctypes.c_float * 3)(*pre.attrs['scale'])
+        self._emit('stem', a['weights'].rsplit('/', 1)[0], 'fss_stem_conv_u8',
+                   (x.ptr, wdev.data_ptr(), bdev.data_ptr(), out.ptr, n, hr, wr, sub, h, w, mean, sc,
+                    cout, kh, kw, a['stride'], a['rate'], a['pad_top'], a['pad_left'], ho, wo,
+                    _lib.ACT_CODES[a['activation']], _CODE[self.dt], out.ld, self.sh),
+                   flops=2 * n * ho * wo * cout * kh * kw * 3,
+                   nbytes=n * (hr // sub) * (wr // sub) * 3 + n * ho * wo * cout * _ESZ[self.dt],
+                   keep=(mean, sc))
+
     def _l_conv(self, ln):
         a = ln.attrs
+        stem = self._stem_source(ln)
+        if stem is not None:
+            return self._l_stem_conv(ln, *stem)
         x = self._val(ln.inputs[0])
         if not x.dense:
             raise NotImplementedError('conv input must be dense')
@@ -557,26 +634,75 @@ class CompiledGraph(object):
         self.vals[ln] = Val(src.buf, ln.shape, src.dt, phys_c=src.phys_c, ld=src.ld, coff=src.coff)
 
     # ------------------------------------------------------------ conv tuning
-    _TUNE_CACHE = {}
+    _TUNE_CACHE = None      # {key string: config}, shared by every plan of the process
+
+    @staticmethod
+    def _tune_file():
+        return os.environ.get('FSS_TUNE_FILE',
+                              os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_tuned.json'))
+
+    @classmethod
+    def _tune_stamp(cls):
+        # library version + the whole configuration table: a table measured with other
+        # kernels or other tile shapes is not reused
+        info, parts = (ctypes.c_int * 7)(), [str(lib.fss_version())]
+        for cfg in range(1, lib.fss_conv_config_count() + 1):
+            _lib.call('fss_conv_config_info', cfg, info)
+            parts.append('x'.join(str(v) for v in info))
+        return '/'.join(parts)
+
+    @classmethod
+    def _tune_load(cls):
+        """Pre-tuned choices shipped next to this module (ignored when they were
+        measured with another kernel table)."""
+        cls._TUNE_CACHE = {}
+        try:
+            with open(cls._tune_file()) as f:
+                d = json.load(f)
+            if d.get('stamp') == cls._tune_stamp():
+                cls._TUNE_CACHE.update({k: int(v) for k, v in d['entries'].items()})
+        except (OSError, ValueError, KeyError):
+            pass
+
+    @classmethod
+    def save_tuning(cls, path=None):
+        """Writes every choice made so far (tools/tune_convs.py calls this)."""
+        with open(path or cls._tune_file(), 'w') as f:
+            json.dump({'stamp': cls._tune_stamp(), 'entries': dict(sorted((cls._TUNE_CACHE or {}).items()))},
+                      f, indent=0)
 
     def _autotune_convs(self, warm=2, reps=4):
-        """Times every tile configuration of the conv kernel on each distinct
-        layer shape (HIP events on the plan's stream) and keeps the fastest.
-        All configurations produce identical results, so this only affects speed."""
+        """Picks the fastest tile configuration of the conv kernel for each distinct
+        layer shape: from the pre-tuned table when the shape is in it, else by timing
+        the candidates (HIP events on the plan's stream).  Only configurations of one
+        MFMA shape (self.mfma_edge) are candidates: inside a shape class results are
+        bit-identical, so the choice affects speed and never the output."""
+        if CompiledGraph._TUNE_CACHE is None:
+            self._tune_load()
+        cache = CompiledGraph._TUNE_CACHE
         ncfg = lib.fss_conv_config_count()
-        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
-        _lib.call('fss_event_create', ctypes.byref(e0))
-        _lib.call('fss_event_create', ctypes.byref(e1))
+        info = (ctypes.c_int * 7)()
+        candidates = []
+        for cfg in range(1, ncfg + 1):
+            _lib.call('fss_conv_config_info', cfg, info)
+            if info[6] == self.mfma_edge:
+                candidates.append(cfg)
+        e0 = e1 = None
         ms = ctypes.c_float()
         for s in self.steps:
             if s.kind != 'conv':
                 continue
             d = s.keep
-            key = tuple(getattr(d, f[0]) for f in d._fields_ if f[0] != 'config') + (s.args[4] is not None,)
-            best = self._TUNE_CACHE.get(key)
+            key = ','.join(str(getattr(d, f[0])) for f in d._fields_ if f[0] != 'config')
+            key += ',%d,%d' % (s.args[4] is not None, self.mfma_edge)
+            best = cache.get(key)
             if best is None:
+                if e0 is None:
+                    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+                    _lib.call('fss_event_create', ctypes.byref(e0))
+                    _lib.call('fss_event_create', ctypes.byref(e1))
                 best, best_ms = 0, float('inf')
-                for cfg in range(1, ncfg + 1):
+                for cfg in candidates:
                     d.config = cfg
                     for _ in range(warm):
                         check(s.fn(*s.args), s.name)
@@ -588,10 +714,12 @@ class CompiledGraph(object):
                     _lib.call('fss_event_elapsed_ms', e0, e1, ctypes.byref(ms))
                     if ms.value < best_ms:
                         best, best_ms = cfg, ms.value
-                self._TUNE_CACHE[key] = best
+                cache[key] = best
+                self.tuned_now += 1
             d.config = best
-        _lib.call('fss_event_destroy', e0)
-        _lib.call('fss_event_destroy', e1)
+        if e0 is not None:
+            _lib.call('fss_event_destroy', e0)
+            _lib.call('fss_event_destroy', e1)
 
     # -------------------------------------------------------------- execution
     def run_eager(self):

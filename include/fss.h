@@ -85,13 +85,20 @@ typedef struct fss_conv_desc {
   int32_t res_ld;            /* residual pixel stride in elements          */
   int32_t k_pad, cout_pad;   /* packed weight dims                         */
   int32_t config;            /* tile configuration: 0 = automatic, else
-                                1..fss_conv_config_count(); results do not
-                                depend on it, only speed does              */
+                                1..fss_conv_config_count(); configurations
+                                with the same mfma_edge (see
+                                fss_conv_config_info) give bit-identical
+                                results, only speed differs                */
 } fss_conv_desc;
 
 int fss_conv_pack_dims(int cin, int kh, int kw, int cout, int dtype,
                        int* k_pad, int* cout_pad);
 int fss_conv_config_count(void);
+/* Geometry of configuration `config` (1..count), for tuners and tests:
+ * info[0..6] = block rows (output pixels), block columns (output channels),
+ * waves along rows, waves along columns, bytes of K per tile row, LDS ring
+ * stages, edge of the MFMA output tile (32: v_mfma_*_32x32, 16: v_mfma_*_16x16). */
+int fss_conv_config_info(int config, int info[7]);
 
 /* y = act(conv(x, W) + bias [+ residual]).
  * Replaces slim.conv2d + slim.batch_norm(inference) + activation
@@ -167,6 +174,29 @@ int fss_copy_channels(const void* x, int x_ld, void* y, int y_ld, size_t pixels,
 int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho,
                       int wo, int c_out, const float* mean3, const float* scale3,
                       int dtype, void* stream);
+
+/* First convolution of a network computed straight from the uint8 frame:
+ *   img[n,i,j,ch] = (frame pixel (i*sub, j*sub), or 0 beyond the hr x wr frame,
+ *                    minus mean[ch]) * scale[ch]       for 0 <= i < h, 0 <= j < w
+ *   y = act(conv(img, W; stride, dilation, zero padding pad_top/pad_left) + bias)
+ * in `dtype` arithmetic (bf16: img and W rounded to bf16, float accumulation)
+ * with `dtype` output, pixel stride y_ld.  `sub` = 2 is the reference's
+ * align_corners half-size resize of the padded frame (its scale is exactly 2,
+ * so it keeps every second pixel).  Fuses tf.image.pad_to_bounding_box +
+ * tf.to_float + extractor.preprocess (libs/exporter.py:37-38,52-53,
+ * extractors/pspnet_icnet_resnet_v1.py:43-45) [+ the 0.5 resize of
+ * architectures/icnet_architecture.py:92-101] + the first slim.conv2d + batch
+ * norm + activation (third_party/dilated_resnet_v1.py conv1,
+ * architectures/icnet_architecture.py:153-160 'Conv',
+ * third_party/mobilenet_v2.py first conv).  Weights: [cout_pad][k_pad] with
+ * k = (r*kw + s)*4 + ch (ch 3 = 0), dims from fss_stem_pack_dims, batch norm
+ * folded in.  Limits: cout <= 64, kh*kw <= 64, stride, dilation <= 4. */
+int fss_stem_pack_dims(int kh, int kw, int cout, int dtype, int* k_pad, int* cout_pad);
+int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const float* bias, void* y,
+                     int n, int hr, int wr, int sub, int h, int w,
+                     const float* mean3, const float* scale3, int cout, int kh, int kw,
+                     int stride, int dilation, int pad_top, int pad_left, int ho, int wo,
+                     int act, int dtype, int y_ld, void* stream);
 
 /* Bilinear (align_corners) upsample of float logits [n,h,w,c] (pixel stride
  * x_ld >= c floats) to [n,ho,wo] fused with argmax over channels (lowest index

@@ -68,3 +68,41 @@ def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw
     if ld != cout:
         assert np.all(out[..., cout:] == -77.0), 'kernel wrote outside its channel slice'
     return out[..., :cout]
+
+
+def pack_stem_weights(w, dt):
+    """[kh,kw,3,cout] -> device [cout_pad][k_pad], k = tap*4 + channel."""
+    kh, kw, cin, cout = w.shape
+    assert cin == 3
+    k_pad, cout_pad = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.call('fss_stem_pack_dims', kh, kw, cout, DT[dt][0], ctypes.byref(k_pad), ctypes.byref(cout_pad))
+    wp = np.zeros((cout_pad.value, k_pad.value), np.float32)
+    w4 = np.pad(w, ((0, 0), (0, 0), (0, 1), (0, 0)))
+    wp[:cout, :kh * kw * 4] = w4.transpose(3, 0, 1, 2).reshape(cout, -1)
+    if dt == 'bf16':
+        return torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
+    return torch.from_numpy(wp).cuda()
+
+
+def stem_conv(frames, w, bias, mean, scale, sub, logical_hw, stride, rate, pads, out_hw, act, dt,
+              y_ld=None):
+    """frames: uint8 [n,hr,wr,3]; returns float32 host array [n,ho,wo,cout]."""
+    n, hr, wr, _ = frames.shape
+    kh, kw, _, cout = w.shape
+    ho, wo = out_hw
+    xd = torch.from_numpy(frames).cuda()
+    wdev = pack_stem_weights(w, dt)
+    bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda()
+    ld = y_ld or cout
+    y = torch.full((n, ho, wo, ld), -77.0, dtype=DT[dt][1], device='cuda')
+    m3 = (ctypes.c_float * 3)(*mean)
+    s3 = (ctypes.c_float * 3)(*scale)
+    torch.cuda.synchronize()
+    _lib.call('fss_stem_conv_u8', xd.data_ptr(), wdev.data_ptr(), bd.data_ptr(), y.data_ptr(),
+              n, hr, wr, sub, logical_hw[0], logical_hw[1], m3, s3, cout, kh, kw, stride, rate,
+              pads[0], pads[1], ho, wo, _lib.ACT_CODES[act], DT[dt][0], ld, None)
+    _lib.call('fss_device_sync')
+    out = to_host(y)
+    if ld != cout:
+        assert np.all(out[..., cout:] == -77.0), 'kernel wrote outside its channel slice'
+    return out[..., :cout]

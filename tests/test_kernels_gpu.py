@@ -106,22 +106,78 @@ def test_conv2d_epilogue(dt, act):
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_conv2d_configs_agree_bitwise(dt):
-    """Every tile configuration accumulates each output over k in the same
-    order: results must be bit-identical, whatever the tuner picks."""
+    """Tile configurations with the same MFMA shape accumulate each output over k
+    in the same order: results must be bit-identical within a shape class, and
+    every configuration (and the automatic choice) must match the oracle."""
     gu, L = _gu(), _lib()
     rng = np.random.default_rng(11)
     n, h, wd, cin, cout = 1, 37, 41, 64, 136
     x = rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32)
     w = rng.normal(0, 0.1, (3, 3, cin, cout)).astype(np.float32)
     bias = rng.normal(0, 1, cout).astype(np.float32)
-    outs = []
-    for cfg in range(0, L.lib.fss_conv_config_count() + 1):
-        outs.append(gu.conv2d(x, w, bias, None, 1, 2, (2, 2), (h, wd), 'relu', dt, config=cfg))
-    for o in outs[1:]:
-        assert np.array_equal(o, outs[0])
     ref = O.relu(O.conv2d(gu.bf16_round(x) if dt == 'bf16' else x,
                           gu.bf16_round(w) if dt == 'bf16' else w, 1, 2, 'SAME', np.float64) + bias)
-    _close(outs[0], ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'conv configs')
+    by_shape = {}
+    for cfg in range(0, L.lib.fss_conv_config_count() + 1):
+        out = gu.conv2d(x, w, bias, None, 1, 2, (2, 2), (h, wd), 'relu', dt, config=cfg)
+        _close(out, ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'conv config %d' % cfg)
+        if cfg:
+            info = (ctypes.c_int * 7)()
+            L.call('fss_conv_config_info', cfg, info)
+            assert info[0] % 32 == 0 and info[1] % 32 == 0 and info[6] in (16, 32)
+            first = by_shape.setdefault(info[6], out)
+            assert np.array_equal(out, first), 'config %d differs inside its shape class' % cfg
+    assert sorted(by_shape) == [16, 32]
+
+
+STEM_CASES = [
+    # frame hw, padded hw, sub, k, stride, rate, cout, act, y_ld
+    ((37, 70), (41, 75), 1, 3, 2, 1, 32, 'relu', None),      # ICNet 'Conv' (full-resolution branch)
+    ((37, 70), (41, 75), 2, 7, 2, 1, 64, 'relu', None),      # resnet conv1 behind the 0.5 resize
+    ((40, 64), (41, 65), 1, 7, 2, 1, 64, 'relu', None),      # PSPNet: conv1 on the padded frame
+    ((23, 45), (23, 45), 1, 3, 1, 2, 24, 'relu6', 32),       # ragged cout, dilation, channel slice
+    ((9, 11), (9, 11), 1, 1, 1, 1, 5, None, None),           # 1x1, tiny
+]
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', STEM_CASES)
+def test_stem_conv_u8_matches_preprocess_resize_conv(case, dt):
+    """fss_stem_conv_u8 == pad_to_bounding_box -> (x - mean) * scale -> [align_corners
+    half-size resize] -> conv (explicit symmetric padding as conv2d_same / SAME) ->
+    bias -> activation of the oracle, built from the separate oracle ops."""
+    gu = _gu()
+    (hr, wr), (hp, wp), sub, k, stride, rate, cout, act, y_ld = case
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    frames = rng.integers(0, 256, (2, hr, wr, 3)).astype(np.uint8)
+    mean, scale = (123.68, 116.779, 103.939), (1.0, 0.5, 2.0)
+    w = rng.normal(0, 0.02, (k, k, 3, cout)).astype(np.float32)
+    bias = rng.normal(0, 1, cout).astype(np.float32)
+    img = O.pad_to_bounding_box(frames.astype(np.float32), hp, wp)
+    img = ((img - np.asarray(mean, np.float32)) * np.asarray(scale, np.float32)).astype(np.float32)
+    if sub == 2:
+        hl, wl = (hp - 1) // 2 + 1, (wp - 1) // 2 + 1
+        half = O.resize_bilinear(img, hl, wl, align_corners=True)
+        assert np.array_equal(half, img[:, ::2, ::2, :])     # the resize is a pure subsampling
+        img = half
+    hl, wl = img.shape[1:3]
+    keff = k + (k - 1) * (rate - 1)
+    if stride > 1 and k > 1:     # conv2d_same: explicit symmetric-ish padding, then VALID
+        pt = (keff - 1) // 2
+        pb = keff - 1 - pt
+        pads = (pt, pb, pt, pb)
+        ho, wo = (hl + keff - 1 - keff) // stride + 1, (wl + keff - 1 - keff) // stride + 1
+    else:
+        ho, pt, pb = O.same_padding(hl, k, stride, rate)
+        wo, pl, pr = O.same_padding(wl, k, stride, rate)
+        pads = (pt, pb, pl, pr)
+    xin, win = (gu.bf16_round(img), gu.bf16_round(w)) if dt == 'bf16' else (img, w)
+    ref = O.conv2d(xin, win, stride, rate, pads, np.float64) + bias
+    ref = {'relu': O.relu, 'relu6': O.relu6, None: lambda v: v}[act](ref)
+    assert ref.shape[1:3] == (ho, wo)
+    got = gu.stem_conv(frames, w, bias, mean, scale, sub, (hl, wl), stride, rate, (pads[0], pads[2]),
+                       (ho, wo), act, dt, y_ld=y_ld)
+    _close(got, ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'stem conv %s' % dt)
 
 
 def test_conv2d_rejects_bad_arguments():

@@ -1,0 +1,55 @@
+"""Times the conv tile configurations for every layer shape of the shipped model
+configurations and writes the winners to a table the plan compiler loads at import
+(fast-semantic-segmentation_amd/fss/conv_tuned.json).
+
+usage (on a GPU box): python tools/tune_convs.py [--out gpurun_out/conv_tuned.json]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'fast-semantic-segmentation_amd')
+sys.path[:0] = [ROOT, PKG, os.path.join(ROOT, 'tools')]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'conv_tuned.json'))
+    ap.add_argument('--fresh', action='store_true', help='ignore the shipped table')
+    args = ap.parse_args()
+    from google.protobuf import text_format
+    from protos import pipeline_pb2
+    from builders import model_builder
+    from fss import graph as G, synth, plan
+    from libs import evaluator
+    from bench_configs import CASES
+    if args.fresh:
+        plan.CompiledGraph._TUNE_CACHE = {}
+    jobs = []
+    for name, (cfg_file, in_shape, pad_shape, batches) in CASES.items():
+        for dtype, edges in (('bfloat16', (16, 32)), ('float32', (32, 16))):
+            for b in batches:
+                if dtype == 'float32' and name not in ('icnet10',):
+                    continue
+                for e in edges:
+                    jobs.append((name, cfg_file, in_shape, pad_shape, b, dtype, e))
+    # the smoke-test / small shapes
+    for name, cfg_file, in_shape, pad_shape, b, dtype, e in jobs:
+        cfg = pipeline_pb2.PipelineConfig()
+        with open(os.path.join(PKG, 'configs', cfg_file)) as f:
+            text_format.Merge(f.read(), cfg)
+        g = G.reset_default_graph()
+        _, model = model_builder.build(cfg.model, is_training=False)
+        preds, _ = evaluator.create_predictions_and_labels(model, in_shape, pad_shape[0], pad_shape[1],
+                                                           False, b)
+        weights = synth.make_weights(g.variables, input_std=0.55 if 'mobilenet' in cfg_file else 70.0)
+        cg = plan.CompiledGraph(g, [preds], weights, dtype=dtype, mfma_edge=e, use_hip_graph=False)
+        print('%s %s b%d edge %d: %d shapes timed' % (name, dtype, b, e, cg.tuned_now), flush=True)
+        del cg
+        plan.CompiledGraph.save_tuning(args.out)
+    print('wrote', args.out, len(plan.CompiledGraph._TUNE_CACHE), 'entries')
+
+
+if __name__ == '__main__':
+    main()
