@@ -167,7 +167,6 @@ conv_igemm_kernel(const ConvArgs a) {
   const T* __restrict__ wgt = reinterpret_cast<const T*>(a.w);
   const void* zero_src = reinterpret_cast<const void*>(g_zero_chunk);
 
-  const int KT = a.Kpad / BK;
   const int HoWo = a.Ho * a.Wo;
 
   // ---- per-row gather state
@@ -207,10 +206,34 @@ conv_igemm_kernel(const ConvArgs a) {
     wptr[i] = reinterpret_cast<const char*>(wgt + (size_t)(tile_n * BN + row0 + i * RSTEP) * a.Kpad +
                                             chunk * EPC);
 
-  // tap walk.  ALIGNED: (cb, kr, ks) = channel base / tap of the whole tile (uniform).
+  // tap walk.  ALIGNED: (kc, tap = kr*KW + ks) = channel base / tap of the whole tile
+  // (uniform); taps that read padding for EVERY row of this block are skipped, and so
+  // is the zero tail of the packed K axis, so the block runs KT <= Kpad/BK tiles.
   // Otherwise: channel kc of tap (kr, ks) of this lane's logical chunk.
-  int kc = ALIGNED ? 0 : chunk * EPC, kr = 0, ks = 0;
-  if constexpr (!ALIGNED) {
+  int kc = ALIGNED ? 0 : chunk * EPC, kr = 0, ks = 0, tap = 0;
+  unsigned long long bmask = 0;              // ALIGNED: taps some row of the block reads for real
+  int KT = a.Kpad / BK;
+  if constexpr (ALIGNED) {
+    __shared__ unsigned long long wave_taps[WAVES_M * WAVES_N];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) mine |= tapmask[i];
+    const int ntaps = a.KH * a.KW;
+    unsigned long long wmask = 0;
+    for (int t = 0; t < ntaps; ++t)
+      if (__ballot((mine >> t) & 1ull) != 0ull) wmask |= 1ull << t;
+    if (lane == 0) wave_taps[wave] = wmask;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < WAVES_M * WAVES_N; ++w) bmask |= wave_taps[w];
+    bmask = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(bmask >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)bmask);
+    KT = __popcll(bmask) * (a.Cin / BK);
+    while (tap < ntaps && !((bmask >> tap) & 1ull)) {
+      ++tap;
+      if (++ks == a.KW) { ks = 0; ++kr; }
+    }
+  } else {
     while (kc >= a.Cin) {
       kc -= a.Cin;
       if (++ks == a.KW) { ks = 0; ++kr; }
@@ -223,12 +246,12 @@ conv_igemm_kernel(const ConvArgs a) {
     const unsigned dstA = smem_base + slot * STAGE_BYTES + wave * 1024;
     const unsigned dstB = dstA + BM * BKB;
     if constexpr (ALIGNED) {
-      const int tap = min(kr * a.KW + ks, 63);          // bit 63 is never set
+      const int tbit = min(tap, 63);                    // bit 63 is never set
       // byte offset of the tap inside one image: fits 32 bits (checked by the host)
       const int tap_off = ((kr * a.dil * a.W + ks * a.dil) * a.Cin + kc) * (int)sizeof(T);
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
-        const bool ok = (tapmask[i] >> tap) & 1ull;
+        const bool ok = (tapmask[i] >> tbit) & 1ull;
         const void* src = ok ? (const void*)(rptr[i] + tap_off) : zero_src;
         glds16(src, dstA + i * (NT * 16));
       }
@@ -245,16 +268,21 @@ conv_igemm_kernel(const ConvArgs a) {
       }
     }
     const bool w_ok = kt < KT;
+    // k index of the tile in the packed weights
+    const size_t wk = ALIGNED ? (size_t)(tap * a.Cin + kc) * sizeof(T) : (size_t)kt * BKB;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-      const void* src = w_ok ? (const void*)(wptr[i] + (size_t)kt * BKB) : zero_src;
+      const void* src = w_ok ? (const void*)(wptr[i] + wk) : zero_src;
       glds16(src, dstB + i * (NT * 16));
     }
     kc += BK;
     if constexpr (ALIGNED) {
       if (kc == a.Cin) {
         kc = 0;
-        if (++ks == a.KW) { ks = 0; ++kr; }
+        do {
+          ++tap;
+          if (++ks == a.KW) { ks = 0; ++kr; }
+        } while (tap < a.KH * a.KW && !((bmask >> tap) & 1ull));
       }
     } else {
       while (kc >= a.Cin) {
@@ -280,6 +308,20 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < MMA::NREG; ++r) acc[i][j][r] = 0.f;
 
+  // ---- epilogue geometry (needed now: the residual is fetched before the main loop)
+  constexpr int SROW = WTN + 4;              // staging row stride in floats
+  static_assert(WAVES_M * WAVES_N * 32 * SROW * 4 <= NSTAGE * STAGE_BYTES,
+                "epilogue staging does not fit in the ring");
+  constexpr int QPR = WTN / 4;               // float4 groups per staged row
+  constexpr int PASSES = 32 * QPR / 64;      // float4 groups per lane per 32-row slab
+  constexpr int SLABS = WTM / 32;
+  TO* __restrict__ yg = reinterpret_cast<TO*>(a.y);
+  const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+  const int n_base = tile_n * BN + wn * WTN;
+  const bool vec_ok = ((a.y_ld & 3) == 0) && ((a.Cout & 3) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
+                      (rg == nullptr ||
+                       (((a.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.res) & 15) == 0)));
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
 
@@ -307,30 +349,46 @@ conv_igemm_kernel(const ConvArgs a) {
     slot = slot + 1 == NSTAGE ? 0 : slot + 1;
     fill = fill + 1 == NSTAGE ? 0 : fill + 1;
   }
-  wait_vmcnt<0>();                           // drain the zero-fill tail pieces
+  // Residual of this lane's output pieces (bf16: 4 values = 8 bytes per piece): loaded
+  // here, where the gather registers are dead, so that its latency overlaps the drain
+  // of the ring, the barrier and the staging of the first slab.  The loads are younger
+  // than every DMA piece, so waiting for all but them drains the ring.
+  constexpr bool RES_PREFETCH = sizeof(T) == 2;
+  uint2 rpre[RES_PREFETCH ? SLABS : 1][RES_PREFETCH ? PASSES : 1];
+  bool drained = false;
+  if constexpr (RES_PREFETCH) {
+    if (rg != nullptr && vec_ok) {
+#pragma unroll
+      for (int sl = 0; sl < SLABS; ++sl)
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+          const int gq = lane + p * 64;
+          const int m = tile_m * BM + wm * WTM + sl * 32 + gq / QPR, n = n_base + (gq % QPR) * 4;
+          const bool ok = m < a.M && n < a.Cout;
+          const T* rp = ok ? rg + (size_t)m * a.res_ld + n : reinterpret_cast<const T*>(g_zero_chunk);
+          rpre[sl][p] = *reinterpret_cast<const uint2*>(rp);
+        }
+      wait_vmcnt<SLABS * PASSES>();
+      drained = true;
+    } else {
+#pragma unroll
+      for (int sl = 0; sl < SLABS; ++sl)
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) rpre[sl][p] = make_uint2(0u, 0u);
+    }
+  }
+  if (!drained) wait_vmcnt<0>();             // drain the zero-fill tail pieces
   __syncthreads();                           // everyone is done with the ring
 
   // ---- epilogue: per wave, 32 rows at a time through LDS (MMA::row_of maps an
   // accumulator register to its row inside the FM x FM tile; the column is lrow).
-  constexpr int SROW = WTN + 4;              // staging row stride in floats
-  static_assert(WAVES_M * WAVES_N * 32 * SROW * 4 <= NSTAGE * STAGE_BYTES,
-                "epilogue staging does not fit in the ring");
   float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SROW);
-  TO* __restrict__ yg = reinterpret_cast<TO*>(a.y);
-  const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
-  const int n_base = tile_n * BN + wn * WTN;
-  constexpr int QPR = WTN / 4;               // float4 groups per staged row
-  constexpr int PASSES = 32 * QPR / 64;      // float4 groups per lane per 32-row slab
   // branch-free activation: none / relu / relu6 as a clamp to [lo, hi]
   const float act_lo = a.act == FSS_ACT_NONE ? -INFINITY : 0.f;
   const float act_hi = a.act == FSS_ACT_RELU6 ? 6.f : INFINITY;
-  const bool vec_ok = ((a.y_ld & 3) == 0) && ((a.Cout & 3) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
-                      (rg == nullptr ||
-                       (((a.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.res) & 15) == 0)));
   constexpr int TPS = 32 / FM;               // MFMA tile rows per 32-row slab
 #pragma unroll
-  for (int sl = 0; sl < WTM / 32; ++sl) {
+  for (int sl = 0; sl < SLABS; ++sl) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n = n_base + j * FM + lrow;
@@ -354,12 +412,11 @@ conv_igemm_kernel(const ConvArgs a) {
         TO* dst = yg + (size_t)m * a.y_ld + n;
         if (vec_ok) {
           if (rg != nullptr) {
-            const T* rp = rg + (size_t)m * a.res_ld + n;
             if constexpr (sizeof(T) == 4) {
-              const float4 r4 = *reinterpret_cast<const float4*>(rp);
+              const float4 r4 = *reinterpret_cast<const float4*>(rg + (size_t)m * a.res_ld + n);
               v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             } else {
-              const uint2 r2 = *reinterpret_cast<const uint2*>(rp);
+              const uint2 r2 = rpre[sl][p];
               v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
               v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
             }
