@@ -310,11 +310,14 @@ conv_igemm_kernel(const ConvArgs a) {
 
   // ---- epilogue geometry (needed now: the residual is fetched before the main loop)
   constexpr int SROW = WTN + 4;              // staging row stride in floats
-  static_assert(WAVES_M * WAVES_N * 32 * SROW * 4 <= NSTAGE * STAGE_BYTES,
+  // rows staged per wave at a time: 32, or 16 when 32 would not fit in the ring
+  constexpr int SLABR = (WAVES_M * WAVES_N * 32 * SROW * 4 <= NSTAGE * STAGE_BYTES) ? 32 : 16;
+  static_assert(WAVES_M * WAVES_N * SLABR * SROW * 4 <= NSTAGE * STAGE_BYTES,
                 "epilogue staging does not fit in the ring");
+  static_assert(SLABR % FM == 0, "a staging slab must hold whole MFMA tiles");
   constexpr int QPR = WTN / 4;               // float4 groups per staged row
-  constexpr int PASSES = 32 * QPR / 64;      // float4 groups per lane per 32-row slab
-  constexpr int SLABS = WTM / 32;
+  constexpr int PASSES = SLABR * QPR / 64;   // float4 groups per lane per slab
+  constexpr int SLABS = WTM / SLABR;
   TO* __restrict__ yg = reinterpret_cast<TO*>(a.y);
   const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
   const int n_base = tile_n * BN + wn * WTN;
@@ -363,7 +366,7 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
           const int gq = lane + p * 64;
-          const int m = tile_m * BM + wm * WTM + sl * 32 + gq / QPR, n = n_base + (gq % QPR) * 4;
+          const int m = tile_m * BM + wm * WTM + sl * SLABR + gq / QPR, n = n_base + (gq % QPR) * 4;
           const bool ok = m < a.M && n < a.Cout;
           const T* rp = ok ? rg + (size_t)m * a.res_ld + n : reinterpret_cast<const T*>(g_zero_chunk);
           rpre[sl][p] = *reinterpret_cast<const uint2*>(rp);
@@ -382,11 +385,11 @@ conv_igemm_kernel(const ConvArgs a) {
 
   // ---- epilogue: per wave, 32 rows at a time through LDS (MMA::row_of maps an
   // accumulator register to its row inside the FM x FM tile; the column is lrow).
-  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * SROW);
+  float* stage = reinterpret_cast<float*>(smem) + wave * (SLABR * SROW);
   // branch-free activation: none / relu / relu6 as a clamp to [lo, hi]
   const float act_lo = a.act == FSS_ACT_NONE ? -INFINITY : 0.f;
   const float act_hi = a.act == FSS_ACT_RELU6 ? 6.f : INFINITY;
-  constexpr int TPS = 32 / FM;               // MFMA tile rows per 32-row slab
+  constexpr int TPS = SLABR / FM;            // MFMA tile rows per slab
 #pragma unroll
   for (int sl = 0; sl < SLABS; ++sl) {
 #pragma unroll
@@ -400,7 +403,7 @@ conv_igemm_kernel(const ConvArgs a) {
           stage[(ti * FM + MMA::row_of(r, lg)) * SROW + j * FM + lrow] = acc[sl * TPS + ti][j][r] + bias;
     }
     __syncthreads();
-    const int m_base = tile_m * BM + wm * WTM + sl * 32;
+    const int m_base = tile_m * BM + wm * WTM + sl * SLABR;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int g = lane + p * 64;
@@ -523,8 +526,10 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   X(23, 64, 64, 2, 2, 64, 4, 16)    \
   X(24, 128, 32, 2, 1, 64, 4, 16)   \
   X(25, 128, 32, 2, 1, 64, 2, 16)   \
-  X(26, 256, 128, 4, 2, 64, 3, 16)
-static constexpr int kNumConvConfigs = 26;
+  X(26, 256, 128, 4, 2, 64, 3, 16)  \
+  X(27, 256, 256, 4, 4, 64, 3, 16)  \
+  X(28, 256, 256, 4, 4, 128, 2, 16)
+static constexpr int kNumConvConfigs = 28;
 
 // automatic choice when the caller does not name a configuration
 static int default_config(const ConvArgs& a) {
@@ -562,7 +567,7 @@ extern "C" int fss_conv_pack_dims(int cin, int kh, int kw, int cout, int dtype, 
   FSS_REQUIRE(cin > 0 && kh > 0 && kw > 0 && cout > 0, "bad shape");
   const int k = cin * kh * kw;
   *k_pad = (k + 63) / 64 * 64;          // a multiple of every K tile in use
-  *cout_pad = (cout + 127) / 128 * 128; // a multiple of every N tile in use
+  *cout_pad = (cout + 255) / 256 * 256; // a multiple of every N tile in use
   return 0;
 }
 

@@ -104,6 +104,11 @@ int fss_event_record(void* event, void* stream) {
   return 0;
 }
 
+int fss_stream_wait_event(void* stream, void* event) {
+  FSS_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return 0;
+}
+
 int fss_event_sync(void* event) {
   FSS_CHECK_HIP(hipEventSynchronize((hipEvent_t)event));
   return 0;

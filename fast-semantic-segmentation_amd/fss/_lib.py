@@ -46,6 +46,7 @@ PROTOTYPES = {
     'fss_event_create': (c_int, [ctypes.POINTER(c_void_p)]),
     'fss_event_destroy': (c_int, [c_void_p]),
     'fss_event_record': (c_int, [c_void_p, c_void_p]),
+    'fss_stream_wait_event': (c_int, [c_void_p, c_void_p]),
     'fss_event_sync': (c_int, [c_void_p]),
     'fss_event_elapsed_ms': (c_int, [c_void_p, c_void_p, c_float_p]),
     'fss_capture_begin': (c_int, [c_void_p]),

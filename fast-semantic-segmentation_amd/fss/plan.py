@@ -21,9 +21,11 @@ Rewrites:
 Device memory, streams and host<->device copies go through torch; all
 arithmetic goes through libfss_gfx950.so.
 """
+import bisect
 import ctypes
 import json
 import os
+import time
 
 import numpy as np
 import torch
@@ -76,11 +78,25 @@ class Val(object):
 
 
 class Step(object):
-    __slots__ = ('kind', 'name', 'fn', 'args', 'flops', 'bytes', 'keep')
+    __slots__ = ('kind', 'name', 'fn', 'args', 'flops', 'bytes', 'keep', 'stream', 'waits', 'signal')
 
     def __init__(self, kind, name, fn, args, flops=0, nbytes=0, keep=None):
-        self.kind, self.name, self.fn, self.args = kind, name, fn, args
+        self.kind, self.name, self.fn, self.args = kind, name, fn, args   # args[-1] is the stream
         self.flops, self.bytes, self.keep = flops, nbytes, keep
+        self.stream = 0         # 0: the plan's stream, 1: the side stream
+        self.waits = []         # events its stream waits for before the launch
+        self.signal = None      # event recorded on its stream after the launch
+
+
+# index of the output-pointer arguments of every kernel entry point (everything else
+# that points into an activation buffer is read)
+_OUT_ARGS = {
+    'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_conv2d_nhwc': (5,),
+    'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
+    'fss_avgpool_bins_nhwc': (1,), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
+    'fss_add_act': (2,), 'fss_copy_channels': (2,), 'fss_upsample_argmax': (1, 2),
+    'fss_label_lut': (1,),
+}
 
 
 class CompiledGraph(object):
@@ -92,7 +108,7 @@ class CompiledGraph(object):
 
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
-                 fuse_stem=True):
+                 fuse_stem=True, streams=2):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
@@ -102,6 +118,7 @@ class CompiledGraph(object):
         self.stream = torch.cuda.Stream(device=self.device)
         self.sh = ctypes.c_void_p(self.stream.cuda_stream)
         self.steps = []
+        self.step_fname = []
         self.vals = {}          # LNode -> Val
         self.lazy = {}          # LNode -> (tag, info..., materialise closure)
         self.keepalive = []     # device-side constants (packed weights, biases, tables)
@@ -113,6 +130,9 @@ class CompiledGraph(object):
         if self.mfma_edge not in (16, 32):
             raise ValueError('mfma_edge must be 16 or 32')
         self.fuse_stem = fuse_stem
+        self.two_streams = False
+        self.release_after = None
+        self.events = []
         self.tuned_now = 0      # layer shapes timed by this plan (0: all came from the table)
         with torch.cuda.device(self.device):
             self._import(graph, outputs, commute_classifier)
@@ -123,6 +143,8 @@ class CompiledGraph(object):
             self.run_eager()
             self.sync()
             if use_hip_graph:
+                if streams > 1:
+                    self._setup_streams()
                 self._capture()
 
     # ---------------------------------------------------- import + rewrites
@@ -210,7 +232,9 @@ class CompiledGraph(object):
         return ln.consumers[0]
 
     def _emit(self, kind, name, fname, args, flops=0, nbytes=0, keep=None):
-        self.steps.append(Step(kind, name, getattr(lib, fname), args, flops, nbytes, keep))
+        st = Step(kind, name, getattr(lib, fname), args, flops, nbytes, keep)
+        self.steps.append(st)
+        self.step_fname.append(fname)
 
     # --------------------------------------------------------------- lowering
     def _lower(self):
@@ -721,12 +745,121 @@ class CompiledGraph(object):
             _lib.call('fss_event_destroy', e0)
             _lib.call('fss_event_destroy', e1)
 
+    # ------------------------------------------------------------ two streams
+    def _dependencies(self):
+        """deps[i] = steps that must finish before step i starts, found from the
+        activation buffers each launch reads and writes (pointer arguments that fall
+        inside a buffer of the plan; _OUT_ARGS says which of them are written)."""
+        ranges, seen = [], set()
+        for v in list(self.vals.values()) + [self.input_val]:
+            t = v.buf
+            if t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                ranges.append((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()))
+        ranges.sort()
+        starts = [r[0] for r in ranges]
+
+        def buf_of(ptr):
+            k = bisect.bisect_right(starts, ptr) - 1
+            return k if k >= 0 and ptr < ranges[k][1] else None
+
+        last_writer, readers, deps, main_src = {}, {}, [], []
+        for i, (s, fname) in enumerate(zip(self.steps, self.step_fname)):
+            outs = _OUT_ARGS[fname]
+            rd, wr = [], []
+            for ai, arg in enumerate(s.args[:-1]):
+                if isinstance(arg, int):
+                    ptrs = [arg]
+                elif isinstance(arg, ctypes.Array) and getattr(arg, '_type_', None) is ctypes.c_void_p:
+                    ptrs = [q for q in arg if q]
+                else:
+                    continue
+                for q in ptrs:
+                    b = buf_of(q)
+                    if b is not None:
+                        (wr if ai in outs else rd).append(b)
+            d = set()
+            for b in rd + wr:
+                if b in last_writer:
+                    d.add(last_writer[b])
+            for b in wr:                      # write after read (slices of a concat buffer)
+                d |= readers.get(b, set())
+            d.discard(i)
+            deps.append(d)
+            main_src.append(last_writer.get(rd[0]) if rd else None)
+            for b in rd:
+                readers.setdefault(b, set()).add(i)
+            for b in wr:
+                last_writer[b] = i
+                readers[b] = set()
+        return deps, main_src
+
+    def _assign_streams(self, release_after=None):
+        """Puts the second chain that starts from the input frame (ICNet's full-resolution
+        branch) on a side stream, with events where the chains exchange data.
+        release_after: index of a step of the main chain the side chain waits for before
+        it starts (None: starts with the main chain)."""
+        deps, main_src = self._dependencies()
+        for s in self.steps:
+            s.stream, s.waits, s.signal = 0, [], None
+        roots = 0
+        for i, s in enumerate(self.steps):
+            if not deps[i]:
+                s.stream = 0 if roots == 0 else 1
+                roots += 1
+            else:
+                src = main_src[i] if main_src[i] is not None else max(deps[i])
+                s.stream = self.steps[src].stream
+        side = [i for i, s in enumerate(self.steps) if s.stream == 1]
+        if not side:
+            return False
+        if release_after is not None:
+            deps[side[0]] = set(deps[side[0]]) | {release_after}
+        synced = {}                               # (from stream, to stream) -> newest step waited for
+
+        def event_of(j):
+            if self.steps[j].signal is None:
+                e = ctypes.c_void_p()
+                _lib.call('fss_event_create', ctypes.byref(e))
+                self.events.append(e)
+                self.steps[j].signal = e
+            return self.steps[j].signal
+
+        for i, s in enumerate(self.steps):
+            for j in sorted(deps[i], reverse=True):
+                sj = self.steps[j].stream
+                if sj != s.stream and synced.get((sj, s.stream), -1) < j:
+                    s.waits.append(event_of(j))
+                    synced[(sj, s.stream)] = j
+        self.join_after = side[-1]
+        event_of(self.join_after)
+        return True
+
     # -------------------------------------------------------------- execution
     def run_eager(self):
+        """One forward pass, launch by launch.  With a side stream: it forks from the
+        plan's stream at the start and joins it at the end, so for callers the whole pass
+        is still ordered on the plan's stream."""
+        if not self.two_streams:
+            for s in self.steps:
+                check(s.fn(*s.args), s.kind + ':' + s.name)
+            return
+        handles = (self.sh, self.sh_side)
+        _lib.call('fss_event_record', self.fork_event, self.sh)
+        _lib.call('fss_stream_wait_event', self.sh_side, self.fork_event)
         for s in self.steps:
-            check(s.fn(*s.args), s.kind + ':' + s.name)
+            h = handles[s.stream]
+            for e in s.waits:
+                _lib.call('fss_stream_wait_event', h, e)
+            check(s.fn(*(s.args[:-1] + (h,))), s.kind + ':' + s.name)
+            if s.signal is not None:
+                _lib.call('fss_event_record', s.signal, h)
+        _lib.call('fss_stream_wait_event', self.sh, self.steps[self.join_after].signal)
 
     def _capture(self):
+        if self.graph_exec is not None:
+            lib.fss_graph_destroy(self.graph_exec)
+            self.graph_exec = None
         _lib.call('fss_capture_begin', self.sh)
         ex = ctypes.c_void_p()
         try:
@@ -734,6 +867,55 @@ class CompiledGraph(object):
         finally:
             _lib.call('fss_capture_end', self.sh, ctypes.byref(ex))
         self.graph_exec = ex
+
+    def _time_launches(self, reps=5):
+        for _ in range(2):
+            self.launch()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            self.launch()
+        self.sync()
+        return (time.perf_counter() - t0) / reps
+
+    def _setup_streams(self, tune=True):
+        """Side-stream schedule; the step of the main chain after which the side chain
+        is released is picked by timing whole passes (memory-bound branch convolutions
+        overlap best with the MFMA-bound part of the backbone, wherever that is)."""
+        self.side_stream = torch.cuda.Stream(device=self.device)
+        self.sh_side = ctypes.c_void_p(self.side_stream.cuda_stream)
+        self.fork_event = ctypes.c_void_p()
+        _lib.call('fss_event_create', ctypes.byref(self.fork_event))
+        self.events.append(self.fork_event)
+        if not self._assign_streams(None):
+            return False
+        self.two_streams = True
+        if not tune:
+            return True
+        side0 = min(i for i, s in enumerate(self.steps) if s.stream == 1)
+        main = [i for i, s in enumerate(self.steps) if s.stream == 0 and i < side0]
+        candidates = [None] + main[max(1, len(main) // 8) - 1::max(1, len(main) // 8)]
+        best, best_t = 'single', None
+        self.two_streams = False
+        self._capture()
+        best_t = single_t = self._time_launches()
+        for c in candidates:
+            self._assign_streams(c)
+            self.two_streams = True
+            self._capture()
+            t = self._time_launches()
+            if os.environ.get('FSS_PLAN_DEBUG'):
+                print('side stream released after step %s: %.3f ms (single stream %.3f ms)'
+                      % (c, t * 1e3, single_t * 1e3), flush=True)
+            if t < best_t:
+                best, best_t = c, t
+        if best == 'single':
+            self.two_streams = False
+        else:
+            self._assign_streams(best)
+            self.two_streams = True
+        self.release_after = best
+        return self.two_streams
 
     def launch(self):
         """Enqueues one forward pass on the plan's stream (asynchronous)."""
@@ -783,6 +965,8 @@ class CompiledGraph(object):
         try:
             if self.graph_exec is not None:
                 lib.fss_graph_destroy(self.graph_exec)
+            for e in self.events:
+                lib.fss_event_destroy(e)
         except Exception:
             pass
 

@@ -55,6 +55,9 @@ int fss_device_sync(void);
 int fss_event_create(void** event);
 int fss_event_destroy(void* event);
 int fss_event_record(void* event, void* stream);
+/* Work enqueued on `stream` after this call waits for `event` (also how a second
+ * stream joins, and leaves, a capture started on another one). */
+int fss_stream_wait_event(void* stream, void* event);
 int fss_event_sync(void* event);
 int fss_event_elapsed_ms(void* start, void* stop, float* ms);
 
