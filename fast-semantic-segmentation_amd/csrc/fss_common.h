@@ -50,6 +50,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// two floats -> two bf16 in one dword (lo in bits 0-15): one v_cvt_pk_bf16_f32
+typedef float fss_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fss_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  fss_f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, fss_bf16x2));
+}
+
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
   static constexpr int kPerChunk = 4;  // elements per 16-byte chunk
@@ -90,8 +98,7 @@ template <> struct Chunk<bf16_t> {
   __device__ __forceinline__ void store(bf16_t* p) const {
     unsigned w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      w[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };

@@ -430,8 +430,8 @@ conv_igemm_kernel(const ConvArgs a) {
             *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
             uint2 o;
-            o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<uint2*>(dst) = o;
           }
         } else {

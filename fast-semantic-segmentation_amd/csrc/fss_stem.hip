@@ -44,8 +44,8 @@ template <typename T> struct StemPix;      // one preprocessed pixel in LDS: 4 x
 template <> struct StemPix<bf16_t> {
   static __device__ __forceinline__ void store(char* p, float a, float b, float c) {
     uint2 o;
-    o.x = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
-    o.y = (unsigned)f32_to_bf16(c);
+    o.x = pack_bf16x2(a, b);
+    o.y = pack_bf16x2(c, 0.f);
     *reinterpret_cast<uint2*>(p) = o;
   }
 };
@@ -112,14 +112,28 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   // logical rows / columns that are frame pixels (the rest of the image is its zero padding)
   const int hreal = min(a.H, (a.Hr + a.sub - 1) / a.sub), wreal = min(a.W, (a.Wr + a.sub - 1) / a.sub);
 
-  struct Tile { int n, oh0, ow0; };
+  // tile index -> (image, first output row, first output column); advanced by gridDim.x
+  // tiles at a time with carries instead of divisions
+  struct Tile { int n, ty, tx, oh0, ow0; };
   auto decode = [&](int tile) {
     Tile t;
     t.n = tile / tiles_per_img;
     const int rem = tile - t.n * tiles_per_img;
-    const int ty = rem / a.tiles_x;
-    t.oh0 = ty * kStemTH;
-    t.ow0 = (rem - ty * a.tiles_x) * a.TW;
+    t.ty = rem / a.tiles_x;
+    t.tx = rem - t.ty * a.tiles_x;
+    t.oh0 = t.ty * kStemTH;
+    t.ow0 = t.tx * a.TW;
+    return t;
+  };
+  const Tile step = decode(gridDim.x);
+  auto advance = [&](Tile t) {
+    t.tx += step.tx;
+    if (t.tx >= a.tiles_x) { t.tx -= a.tiles_x; ++t.ty; }
+    t.ty += step.ty;
+    if (t.ty >= a.tiles_y) { t.ty -= a.tiles_y; ++t.n; }
+    t.n += step.n;
+    t.oh0 = t.ty * kStemTH;
+    t.ow0 = t.tx * a.TW;
     return t;
   };
 
@@ -174,8 +188,8 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
     commit(cur, ureg);
     __syncthreads();
     const Tile now = cur;
-    // past the last tile this re-reads the last one: harmless, and keeps the loop branch-free
-    cur = decode(min(tile + (int)gridDim.x, a.total_tiles - 1));
+    // past the last tile this re-reads the current one: harmless, and keeps the loop branch-free
+    if (tile + (int)gridDim.x < a.total_tiles) cur = advance(cur);
     fetch(cur, ureg);
 
     f32x4 acc[4][NJ];
@@ -247,7 +261,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
           unsigned o[2 * NJ];
 #pragma unroll
           for (int e = 0; e < 2 * NJ; ++e)
-            o[e] = (unsigned)f32_to_bf16(v[2 * e]) | ((unsigned)f32_to_bf16(v[2 * e + 1]) << 16);
+            o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
           if constexpr (NJ % 2 == 0) {
 #pragma unroll
             for (int e = 0; e < NJ / 2; ++e)

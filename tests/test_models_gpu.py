@@ -231,3 +231,34 @@ def test_cli_inference_from_checkpoint(tmp_path):
                                  (256, 512, 3), (257, 513), CITYSCAPES_LABEL_IDS)
     assert got.shape == (256, 512) and got.dtype == np.uint8
     assert (got == ref[0, :, :, 0].astype(np.uint8)).mean() >= 0.999
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_side_stream_and_stem_fusion_do_not_change_results(dtype):
+    """The two-stream schedule only reorders launches along true data dependencies, and
+    the plan picks tile configurations inside one MFMA shape class, so logits must be
+    bit-identical to the single-stream plan; the fused uint8 stem convolution must agree
+    with the unfused preprocess -> resize -> conv path to rounding."""
+    from fss import plan
+    arch, ext, fs, pf, in_shape, pad_shape = CASES[0]
+    g, cfg, outs, weights = build(arch, ext, fs, pf, in_shape, pad_shape)
+    img = np.random.default_rng(3).integers(0, 256, in_shape).astype(np.uint8)
+    got = {}
+    for key, kw in (('two', dict(streams=2)), ('one', dict(streams=1)),
+                    ('eager', dict(streams=2, use_hip_graph=False)),
+                    ('unfused', dict(streams=1, fuse_stem=False))):
+        cg = plan.CompiledGraph(g, outs, weights, dtype=dtype, **kw)
+        if key == 'two':
+            assert cg.two_streams or cg.release_after == 'single'
+            assert any(s.stream == 1 for s in cg.steps), 'ICNet must have a side chain'
+            assert any(s.kind == 'stem' for s in cg.steps)
+        if key == 'unfused':
+            assert not any(s.kind == 'stem' for s in cg.steps)
+        got[key] = cg.run(img)
+        del cg
+    for key in ('one', 'eager'):
+        assert np.array_equal(got['two'][0], got[key][0]), key
+        assert np.array_equal(got['two'][1], got[key][1]), key
+    scale = float(np.abs(got['unfused'][0]).max())
+    err = float(np.abs(got['two'][0] - got['unfused'][0]).max()) / scale
+    assert err <= (1e-5 if dtype == 'float32' else 2e-2), err
