@@ -1,4 +1,4 @@
-"""Throughput / latency of every BASELINE.json configuration (synthetic weights).
+"""Throughput / latency of every shipped model configuration (synthetic weights).
 
 usage: python tools/bench_configs.py [--dtype bfloat16|float32] [names...]
 Prints one line per (config, batch): frames/s, ms/step, conv TFLOP/s and the
