@@ -169,6 +169,9 @@ conv_igemm_kernel(const ConvArgs a) {
 
   const int HoWo = a.Ho * a.Wo;
 
+  // 1x1, stride 1, unpadded: the A matrix is the input tensor itself
+  const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 &&
+                         a.Ho == a.H && a.Wo == a.W;
   // ---- per-row gather state
   // ALIGNED: rptr = address of this lane's chunk at tap (0,0), tapmask bit t = tap t
   //          of this row reads a real pixel.  Otherwise: explicit coordinates.
@@ -180,15 +183,23 @@ conv_igemm_kernel(const ConvArgs a) {
     const int m = tile_m * BM + row0 + i * RSTEP;
     int n = 0, oh = 0, ow = 0;
     const bool row_ok = m < a.M;
-    if (row_ok) {
-      n = m / HoWo;
-      const int rem = m - n * HoWo;
-      oh = rem / a.Wo;
-      ow = rem - oh * a.Wo;
+    long long pix;
+    if (pointwise) {
+      // output pixel m reads input pixel m: no coordinates needed (the tap is always
+      // inside the image; (0, 0) stands in for the real position)
+      ih0[i] = iw0[i] = row_ok ? 0 : -(1 << 28);
+      pix = row_ok ? m : 0;
+    } else {
+      if (row_ok) {
+        n = m / HoWo;
+        const int rem = m - n * HoWo;
+        oh = rem / a.Wo;
+        ow = rem - oh * a.Wo;
+      }
+      ih0[i] = row_ok ? oh * a.stride - a.pad_t : -(1 << 28);
+      iw0[i] = row_ok ? ow * a.stride - a.pad_l : -(1 << 28);
+      pix = ((long long)n * a.H + (row_ok ? ih0[i] : 0)) * a.W + (row_ok ? iw0[i] : 0);
     }
-    ih0[i] = row_ok ? oh * a.stride - a.pad_t : -(1 << 28);
-    iw0[i] = row_ok ? ow * a.stride - a.pad_l : -(1 << 28);
-    const long long pix = ((long long)n * a.H + (row_ok ? ih0[i] : 0)) * a.W + (row_ok ? iw0[i] : 0);
     rptr[i] = reinterpret_cast<const char*>(xg) + (pix * a.Cin + chunk * EPC) * (long long)sizeof(T);
     tapmask[i] = 0;
     if constexpr (ALIGNED) {
