@@ -539,8 +539,12 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   X(25, 128, 32, 2, 1, 64, 2, 16)   \
   X(26, 256, 128, 4, 2, 64, 3, 16)  \
   X(27, 256, 256, 4, 4, 64, 3, 16)  \
-  X(28, 256, 256, 4, 4, 128, 2, 16)
-static constexpr int kNumConvConfigs = 28;
+  X(28, 256, 256, 4, 4, 128, 2, 16) \
+  X(29, 128, 128, 2, 4, 128, 2, 16) \
+  X(30, 128, 128, 4, 2, 128, 2, 16) \
+  X(31, 128, 128, 2, 4, 64, 3, 16)  \
+  X(32, 128, 64, 4, 2, 128, 2, 16)
+static constexpr int kNumConvConfigs = 32;
 
 // automatic choice when the caller does not name a configuration
 static int default_config(const ConvArgs& a) {
