@@ -139,10 +139,15 @@ conv_igemm_kernel(const ConvArgs a) {
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / FM, NI = WTN / FM;
   constexpr int STAGE_BYTES = (BM + BN) * BKB;
-  constexpr int SWZ_SHIFT = CPR == 4 ? 2 : 1;   // rows that share a bank window
+  // XOR term of the chunk index of a tile row.  ds_read_b128 serves a wave in four fixed
+  // groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32); with
+  // these terms the 16 (row, chunk) pairs of every group fall on 16 different 16-byte
+  // bank windows, for both MFMA shapes (32-row fragments: one chunk per group; 16-row
+  // fragments: two chunks per group).  Invariant under row += 16.
+  auto swizzle_of = [](int row) { return CPR == 4 ? ((0 - (row >> 2)) & 3) : ((row >> 1) & 7); };
   static_assert(CPR == 4 || CPR == 8, "BKB must be 64 or 128");
   static_assert(A_CHUNKS % NT == 0 && B_CHUNKS % NT == 0, "tile must split evenly over threads");
-  static_assert(RSTEP % 32 == 0, "row step must keep the swizzle term lane-invariant");
+  static_assert(RSTEP % 16 == 0, "row step must keep the swizzle term lane-invariant");
   static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32x32");
   static_assert(NSTAGE >= 2 && (NSTAGE - 2) * LOADS <= 63, "ring too deep for vmcnt");
 
@@ -161,7 +166,7 @@ conv_igemm_kernel(const ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int row0 = tid / CPR;
   // this lane fills physical chunk (tid % CPR) of its rows with logical chunk `chunk`
-  const int chunk = (tid % CPR) ^ ((row0 >> SWZ_SHIFT) & (CPR - 1));
+  const int chunk = (tid % CPR) ^ swizzle_of(row0);
 
   const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ wgt = reinterpret_cast<const T*>(a.w);
@@ -305,7 +310,7 @@ conv_igemm_kernel(const ConvArgs a) {
 
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int lrow = lane & (FM - 1), lg = lane / FM;
-  const int swz = (lrow >> SWZ_SHIFT) & (CPR - 1);
+  const int swz = swizzle_of(lrow);
   // byte offset, inside a row, of the fragment this lane reads at k step s
   int frag_off[KSTEPS];
 #pragma unroll
