@@ -248,6 +248,99 @@ __global__ void copy_channels_kernel(const T* __restrict__ x, int x_ld, T* __res
       *reinterpret_cast<const uint4*>(x + p * x_ld + ch * E);
 }
 
+// ------------------------------------------------------- pyramid average pooling
+// All bin-average maps of a pyramid pooling module in one pass over the input.
+// Stage 1: one thread per (image row, 16-byte channel chunk) walks the row once and
+// emits, for every level, the sums of its column bins (float).  Stage 2 adds the kh rows
+// of each bin, scales and rounds.  The row sums live in a caller-provided workspace.
+constexpr int kPyrLevels = 4;
+struct PyrArgs {
+  int L, total_cols, total_bins;
+  int kh[kPyrLevels], kw[kPyrLevels], bh[kPyrLevels], bw[kPyrLevels];
+  int col_off[kPyrLevels], bin_off[kPyrLevels];
+  void* y[kPyrLevels];
+};
+
+template <typename T>
+__global__ void pyramid_rowsum_kernel(const T* __restrict__ x, float* __restrict__ part, int N, int H,
+                                      int W, int C, PyrArgs a) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const size_t total = (size_t)N * H * cc;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % cc);
+  const size_t nr = idx / cc;                       // n * H + r
+  const T* row = x + nr * W * C + (size_t)ch * E;
+  float* out = part + nr * a.total_cols * C + (size_t)ch * E;
+  float acc[kPyrLevels][E];
+  int cnt[kPyrLevels], bin[kPyrLevels];
+#pragma unroll
+  for (int l = 0; l < kPyrLevels; ++l) {
+    cnt[l] = bin[l] = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[l][e] = 0.f;
+  }
+#pragma unroll 4
+  for (int col = 0; col < W; ++col) {
+    Chunk<T> v;
+    v.load(row + (size_t)col * C);
+#pragma unroll
+    for (int l = 0; l < kPyrLevels; ++l) {
+      if (l < a.L && bin[l] < a.bw[l]) {            // uniform over the block
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[l][e] += v.v[e];
+        if (++cnt[l] == a.kw[l]) {
+          float* o = out + (size_t)(a.col_off[l] + bin[l]) * C;
+#pragma unroll
+          for (int e = 0; e < E; e += 4)
+            *reinterpret_cast<float4*>(o + e) =
+                make_float4(acc[l][e], acc[l][e + 1], acc[l][e + 2], acc[l][e + 3]);
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[l][e] = 0.f;
+          cnt[l] = 0;
+          ++bin[l];
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void pyramid_binavg_kernel(const float* __restrict__ part, int N, int H, int C, PyrArgs a) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const size_t total = (size_t)N * a.total_bins * cc;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % cc);
+  size_t p = idx / cc;
+  const int b = (int)(p % a.total_bins);
+  const int n = (int)(p / a.total_bins);
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < kPyrLevels; ++k)
+    if (k < a.L && b >= a.bin_off[k]) l = k;
+  const int lb = b - a.bin_off[l];
+  const int by = lb / a.bw[l], bx = lb - by * a.bw[l];
+  float s[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  for (int r = by * a.kh[l]; r < (by + 1) * a.kh[l]; ++r) {
+    const float* q = part + (((size_t)n * H + r) * a.total_cols + a.col_off[l] + bx) * C + (size_t)ch * E;
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(q + e);
+      s[e] += v.x; s[e + 1] += v.y; s[e + 2] += v.z; s[e + 3] += v.w;
+    }
+  }
+  const float inv = 1.f / (float)(a.kh[l] * a.kw[l]);
+  Chunk<T> o;
+#pragma unroll
+  for (int e = 0; e < E; ++e) o.v[e] = s[e] * inv;
+  o.store(reinterpret_cast<T*>(a.y[l]) + (((size_t)n * a.bh[l] + by) * a.bw[l] + bx) * C + (size_t)ch * E);
+}
+
 // ---------------------------------------------------------------- preprocess
 struct PreArgs { float mean[3], scale[3]; };
 
@@ -550,6 +643,56 @@ int fss_avgpool_bins_nhwc(const void* x, void* y, int n, int h, int wd, int c, i
   else
     hipLaunchKernelGGL((avgpool_bins_kernel<bf16_t, TX, TY>), grid, dim3(TX, TY), 0, s,
                        (const bf16_t*)x, (bf16_t*)y, h, wd, c, kh, kw, bh, bw);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_avgpool_pyramid_nhwc(const void* x, void* const* y, const int* kh, const int* kw,
+                             const int* bh, const int* bw, int levels, float* workspace,
+                             size_t workspace_bytes, int n, int h, int wd, int c, int dtype,
+                             void* stream) {
+  FSS_REQUIRE(x && y && kh && kw && bh && bw && workspace, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_CHUNK_OK(c, dtype);
+  FSS_ALIGNED(x); FSS_ALIGNED(workspace);
+  FSS_REQUIRE(levels >= 1 && levels <= kPyrLevels, "between 1 and 4 levels");
+  FSS_REQUIRE(n > 0 && h > 0 && wd > 0, "bad shape");
+  PyrArgs a;
+  a.L = levels;
+  a.total_cols = a.total_bins = 0;
+  for (int l = 0; l < kPyrLevels; ++l) {
+    a.kh[l] = a.kw[l] = a.bh[l] = a.bw[l] = 1;
+    a.col_off[l] = a.bin_off[l] = 0;
+    a.y[l] = nullptr;
+  }
+  for (int l = 0; l < levels; ++l) {
+    FSS_REQUIRE(y[l] != nullptr, "null output");
+    FSS_ALIGNED(y[l]);
+    FSS_REQUIRE(kh[l] > 0 && kw[l] > 0 && bh[l] > 0 && bw[l] > 0, "bad level");
+    FSS_REQUIRE((long long)bh[l] * kh[l] <= h && (long long)bw[l] * kw[l] <= wd, "bins exceed the input");
+    a.kh[l] = kh[l]; a.kw[l] = kw[l]; a.bh[l] = bh[l]; a.bw[l] = bw[l];
+    a.col_off[l] = a.total_cols;
+    a.bin_off[l] = a.total_bins;
+    a.total_cols += bw[l];
+    a.total_bins += bh[l] * bw[l];
+    a.y[l] = y[l];
+  }
+  FSS_REQUIRE(workspace_bytes >= (size_t)n * h * a.total_cols * c * sizeof(float),
+              "workspace smaller than n*h*sum(bw)*c floats");
+  const int cc = c / (dtype == FSS_F32 ? 4 : 8);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t t1 = (size_t)n * h * cc, t2 = (size_t)n * a.total_bins * cc;
+  if (dtype == FSS_F32) {
+    hipLaunchKernelGGL(pyramid_rowsum_kernel<float>, dim3(grid_for(t1)), dim3(kBlock), 0, s,
+                       (const float*)x, workspace, n, h, wd, c, a);
+    hipLaunchKernelGGL(pyramid_binavg_kernel<float>, dim3(grid_for(t2)), dim3(kBlock), 0, s,
+                       workspace, n, h, c, a);
+  } else {
+    hipLaunchKernelGGL(pyramid_rowsum_kernel<bf16_t>, dim3(grid_for(t1)), dim3(kBlock), 0, s,
+                       (const bf16_t*)x, workspace, n, h, wd, c, a);
+    hipLaunchKernelGGL(pyramid_binavg_kernel<bf16_t>, dim3(grid_for(t2)), dim3(kBlock), 0, s,
+                       workspace, n, h, c, a);
+  }
   FSS_LAUNCH_CHECK();
   return 0;
 }

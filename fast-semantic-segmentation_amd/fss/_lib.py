@@ -65,6 +65,8 @@ PROTOTYPES = {
     'fss_subsample_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     'fss_avgpool_bins_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     'fss_resize_bilinear_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    'fss_avgpool_pyramid_nhwc': (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_int_p, c_int_p, c_int_p, c_int_p,
+                                         c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'fss_pyramid_add_nhwc': (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_int_p, c_int_p,
                                      c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'fss_add_act': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),

@@ -93,7 +93,7 @@ class Step(object):
 _OUT_ARGS = {
     'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_conv2d_nhwc': (5,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
-    'fss_avgpool_bins_nhwc': (1,), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
+    'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1,), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
     'fss_add_act': (2,), 'fss_copy_channels': (2,), 'fss_upsample_argmax': (1, 2),
     'fss_label_lut': (1,),
 }
@@ -108,7 +108,7 @@ class CompiledGraph(object):
 
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
-                 fuse_stem=True, streams=2):
+                 fuse_stem=True, streams=2, fuse_pyramid_pool=True):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
@@ -130,6 +130,7 @@ class CompiledGraph(object):
         if self.mfma_edge not in (16, 32):
             raise ValueError('mfma_edge must be 16 or 32')
         self.fuse_stem = fuse_stem
+        self.fuse_pyramid_pool = fuse_pyramid_pool
         self.two_streams = False
         self.release_after = None
         self.events = []
@@ -487,11 +488,36 @@ class CompiledGraph(object):
                        nbytes=(n * h * w * c + n * ho * wo * c) * _ESZ[x.dt])
 
     def _l_avgpool(self, ln):
+        if ln in self.vals:                 # already produced with its siblings (below)
+            return
         a = ln.attrs
         x = self._val(ln.inputs[0])
         if not x.dense:
             raise NotImplementedError('pool input must be dense')
         n, h, w, c = x.shape
+        # the levels of a pyramid pooling module read the same tensor: one pass for all
+        sibs = [s for s in ln.inputs[0].consumers if s.kind == 'avg_pool' and s not in self.vals]
+        if 2 <= len(sibs) <= 4 and self.fuse_pyramid_pool:
+            L = len(sibs)
+            outs = []
+            for s_ in sibs:
+                v = Val(self._alloc(s_.shape, x.dt), s_.shape, x.dt)
+                self.vals[s_] = v
+                outs.append(v)
+            ptrs = (ctypes.c_void_p * L)(*[v.ptr for v in outs])
+            kh = (ctypes.c_int * L)(*[s_.attrs['kh'] for s_ in sibs])
+            kw = (ctypes.c_int * L)(*[s_.attrs['kw'] for s_ in sibs])
+            bh = (ctypes.c_int * L)(*[s_.shape[1] for s_ in sibs])
+            bw = (ctypes.c_int * L)(*[s_.shape[2] for s_ in sibs])
+            cols = sum(s_.shape[2] for s_ in sibs)
+            work = torch.empty((n * h * cols * c,), dtype=torch.float32, device=self.device)
+            self.keepalive.append(work)
+            self._emit('avgpool', 'avg_pool_pyramid', 'fss_avgpool_pyramid_nhwc',
+                       (x.ptr, ptrs, kh, kw, bh, bw, L, work.data_ptr(), work.numel() * 4, n, h, w, c,
+                        _CODE[x.dt], self.sh),
+                       nbytes=n * h * w * c * _ESZ[x.dt] + 2 * work.numel() * 4,
+                       keep=(ptrs, kh, kw, bh, bw))
+            return
         _, bh, bw, _ = ln.shape
         out = Val(self._alloc(ln.shape, x.dt), ln.shape, x.dt)
         self.vals[ln] = out

@@ -142,6 +142,18 @@ int fss_subsample_nhwc(const void* x, void* y, int n, int h, int wd, int c,
 int fss_avgpool_bins_nhwc(const void* x, void* y, int n, int h, int wd, int c,
                           int kh, int kw, int bh, int bw, int dtype, void* stream);
 
+/* The `levels` (<= 4) bin-average maps of one pyramid pooling module in a single
+ * pass over x: level l is fss_avgpool_bins_nhwc with (kh[l],kw[l],bh[l],bw[l]) and
+ * output y[l].  Replaces the loop over pooling factors
+ * (architectures/icnet_architecture.py:194-205,
+ * architectures/pspnet_architecture.py:127-141).  `workspace` is caller-owned
+ * device memory of at least n*h*sum(bw)*c floats (row sums between the two
+ * launches); the entry point itself allocates nothing. */
+int fss_avgpool_pyramid_nhwc(const void* x, void* const* y, const int* kh, const int* kw,
+                             const int* bh, const int* bw, int levels, float* workspace,
+                             size_t workspace_bytes, int n, int h, int wd, int c, int dtype,
+                             void* stream);
+
 /* tf.image.resize_bilinear (TF 1.x legacy sampling), optional align_corners.
  * Replaces architectures/icnet_architecture.py:249,264-266,
  * architectures/pspnet_architecture.py:136-139,158-160,

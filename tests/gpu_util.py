@@ -106,3 +106,22 @@ def stem_conv(frames, w, bias, mean, scale, sub, logical_hw, stride, rate, pads,
     if ld != cout:
         assert np.all(out[..., cout:] == -77.0), 'kernel wrote outside its channel slice'
     return out[..., :cout]
+
+
+def avgpool_pyramid(x, levels, dt):
+    """x: [n,h,w,c] host array; levels: list of (kh, kw); returns the list of bin maps."""
+    n, h, w, c = x.shape
+    xd = to_dev(x, dt)
+    L = len(levels)
+    outs = [torch.full((n, h // kh, w // kw, c), -77.0, dtype=DT[dt][1], device='cuda') for kh, kw in levels]
+    ptrs = (ctypes.c_void_p * L)(*[o.data_ptr() for o in outs])
+    kh = (ctypes.c_int * L)(*[l[0] for l in levels])
+    kw = (ctypes.c_int * L)(*[l[1] for l in levels])
+    bh = (ctypes.c_int * L)(*[h // l[0] for l in levels])
+    bw = (ctypes.c_int * L)(*[w // l[1] for l in levels])
+    work = torch.empty((n * h * sum(bw) * c,), dtype=torch.float32, device='cuda')
+    torch.cuda.synchronize()
+    _lib.call('fss_avgpool_pyramid_nhwc', xd.data_ptr(), ptrs, kh, kw, bh, bw, L, work.data_ptr(),
+              work.numel() * 4, n, h, w, c, DT[dt][0], None)
+    _lib.call('fss_device_sync')
+    return [to_host(o) for o in outs]

@@ -167,7 +167,7 @@ def test_cabi_exports_every_declared_symbol():
     from fss import _lib
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     assert _lib.lib.fss_version() >= 100
-    assert _lib.conv_pack_dims(8, 3, 3, 19, _lib.BF16) == (128, 128)
+    assert _lib.conv_pack_dims(8, 3, 3, 19, _lib.BF16) == (128, 256)
     assert _lib.lib.fss_conv_pack_dims(0, 3, 3, 19, 0, None, None) != 0
     assert b'null' in _lib.lib.fss_last_error()
 

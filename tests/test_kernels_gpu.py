@@ -251,6 +251,14 @@ def test_pools_and_subsample(dt):
             _call('fss_avgpool_bins_nhwc', xd.data_ptr(), y.data_ptr(), n, h, wd, c, kh, kw,
                   ref.shape[1], ref.shape[2], code, None)
             _close(gu.to_host(y), ref, 1e-5 if dt == 'f32' else 1.0 / 128, 'avgpool f=%d' % f)
+        # all levels of a pyramid pooling module in one pass (dropped remainders included)
+        for factors in ((1, 2, 3, 4), (1, 2, 3, 6), (2,)):
+            levels = [(int(h / f), int(wd / f)) for f in factors]
+            got = gu.avgpool_pyramid(x, levels, dt)
+            for (kh, kw), g in zip(levels, got):
+                ref = O.avg_pool_valid(x.astype(np.float64), kh, kw)
+                assert g.shape == ref.shape
+                _close(g, ref, 1e-5 if dt == 'f32' else 1.0 / 128, 'pyramid avgpool %dx%d' % (kh, kw))
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
