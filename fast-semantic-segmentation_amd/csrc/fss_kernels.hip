@@ -182,41 +182,67 @@ struct PyramidArgs {
   int levels;
 };
 
+// One block per (image, output row, group of kPyrPix pixels); threads run over the
+// 16-byte channel chunks, so all coordinates are block-uniform.  Per level the two bin
+// rows are blended vertically once per column pair (v0, v1 - v0), which adjacent pixels
+// share, and each pixel adds v0 + (v1 - v0) * lx.  (The reference blends horizontally
+// first; the two orders agree to float rounding.)
+constexpr int kPyrPix = 8;
 template <typename T>
 __global__ void pyramid_add_kernel(const T* __restrict__ x, T* __restrict__ y, PyramidArgs a, int N,
                                    int H, int W, int C) {
   constexpr int E = Chunk<T>::N;
   const int cc = C / E;
-  const size_t total = (size_t)N * H * W * cc;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int ch = (int)(idx % cc);
-  size_t p = idx / cc;
-  const int ow = (int)(p % W); p /= W;
-  const int oh = (int)(p % H);
-  const int n = (int)(p / H);
-  Chunk<T> acc;
-  acc.load(x + idx * E);
-  for (int l = 0; l < a.levels; ++l) {
-    const int bh = a.bh[l], bw = a.bw[l];
-    int y0, y1, x0, x1;
-    float ly, lx;
-    interp_coord(oh, a.sh[l], bh, y0, y1, ly);
-    interp_coord(ow, a.sw[l], bw, x0, x1, lx);
-    const T* b = reinterpret_cast<const T*>(a.p[l]) + (size_t)n * bh * bw * C + ch * E;
-    Chunk<T> tl, tr, bl, br;
-    tl.load(b + ((size_t)y0 * bw + x0) * C);
-    tr.load(b + ((size_t)y0 * bw + x1) * C);
-    bl.load(b + ((size_t)y1 * bw + x0) * C);
-    br.load(b + ((size_t)y1 * bw + x1) * C);
+  const int groups = (W + kPyrPix - 1) / kPyrPix;
+  int b = blockIdx.x;
+  const int g = b % groups; b /= groups;
+  const int oh = b % H;
+  const int n = b / H;
+  const int ow0 = g * kPyrPix;
+  const size_t row_base = (((size_t)n * H + oh) * W + ow0) * C;
+  for (int ch = threadIdx.x; ch < cc; ch += blockDim.x) {
+    Chunk<T> acc[kPyrPix];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const float top = tl.v[e] + (tr.v[e] - tl.v[e]) * lx;
-      const float bot = bl.v[e] + (br.v[e] - bl.v[e]) * lx;
-      acc.v[e] += top + (bot - top) * ly;
+    for (int k = 0; k < kPyrPix; ++k)
+      if (ow0 + k < W) acc[k].load(x + row_base + (size_t)k * C + (size_t)ch * E);
+    for (int l = 0; l < a.levels; ++l) {
+      const int bh = a.bh[l], bw = a.bw[l];
+      int y0, y1;
+      float ly;
+      interp_coord(oh, a.sh[l], bh, y0, y1, ly);
+      const T* pb = reinterpret_cast<const T*>(a.p[l]) + (size_t)n * bh * bw * C + (size_t)ch * E;
+      const T* r0 = pb + (size_t)y0 * bw * C;
+      const T* r1 = pb + (size_t)y1 * bw * C;
+      int px0 = -1, px1 = -1;
+      float v0[E], dv[E];
+#pragma unroll
+      for (int k = 0; k < kPyrPix; ++k) {
+        if (ow0 + k < W) {
+          int x0, x1;
+          float lx;
+          interp_coord(ow0 + k, a.sw[l], bw, x0, x1, lx);
+          if (x0 != px0 || x1 != px1) {             // block-uniform
+            Chunk<T> tl, tr, bl, br;
+            tl.load(r0 + (size_t)x0 * C);
+            bl.load(r1 + (size_t)x0 * C);
+            tr.load(r0 + (size_t)x1 * C);
+            br.load(r1 + (size_t)x1 * C);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              v0[e] = tl.v[e] + (bl.v[e] - tl.v[e]) * ly;
+              dv[e] = tr.v[e] + (br.v[e] - tr.v[e]) * ly - v0[e];
+            }
+            px0 = x0; px1 = x1;
+          }
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[k].v[e] += v0[e] + dv[e] * lx;
+        }
+      }
     }
+#pragma unroll
+    for (int k = 0; k < kPyrPix; ++k)
+      if (ow0 + k < W) acc[k].store(y + row_base + (size_t)k * C + (size_t)ch * E);
   }
-  acc.store(y + idx * E);
 }
 
 // ------------------------------------------------------------------- add+act
@@ -738,13 +764,16 @@ int fss_pyramid_add_nhwc(const void* x, const void* const* p, const int* bh, con
     a.sh[l] = resize_scale(bh[l], h, 1);
     a.sw[l] = resize_scale(bw[l], wd, 1);
   }
-  const size_t total = (size_t)n * h * wd * (c / (dtype == FSS_F32 ? 4 : 8));
+  const int cc = c / (dtype == FSS_F32 ? 4 : 8);
+  const long long blocks = (long long)n * h * ((wd + kPyrPix - 1) / kPyrPix);
+  FSS_REQUIRE(blocks < 0x7fffffffLL, "too many pixels");
+  const int threads = cc >= 256 ? 256 : (cc >= 128 ? 128 : 64);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == FSS_F32)
-    hipLaunchKernelGGL(pyramid_add_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(pyramid_add_kernel<float>, dim3((unsigned)blocks), dim3(threads), 0, s,
                        (const float*)x, (float*)y, a, n, h, wd, c);
   else
-    hipLaunchKernelGGL(pyramid_add_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(pyramid_add_kernel<bf16_t>, dim3((unsigned)blocks), dim3(threads), 0, s,
                        (const bf16_t*)x, (bf16_t*)y, a, n, h, wd, c);
   FSS_LAUNCH_CHECK();
   return 0;
