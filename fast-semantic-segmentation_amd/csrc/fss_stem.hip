@@ -140,9 +140,10 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   // Reads the frame bytes of the patch of tile t: slot k of a lane is patch pixel
   // (wave + 4k, lane).  Branch-free: slots that are not frame pixels read byte 0 of the
   // frame and are replaced at commit, so every load is in flight before any is used.
-  auto fetch = [&](const Tile& t, unsigned (&u)[kStemRows][3]) {
+  auto fetch = [&](const Tile& t, unsigned (&u)[kStemRows]) {
     const int i0 = t.oh0 * a.stride - a.pad_t, j0 = t.ow0 * a.stride - a.pad_l;
     const uint8_t* frame = a.x + (size_t)t.n * a.Hr * a.Wr * 3;
+    const unsigned last_word = t.n == a.N - 1 ? (unsigned)(a.Hr * a.Wr * 3 - 4) : 0xffffffffu;
     const int j = j0 + lane;
     const bool col_real = lane < a.PW && (unsigned)j < (unsigned)wreal;
     const unsigned coloff = __umul24(j, colstride);       // < 2^31 with the row part: host check
@@ -151,11 +152,14 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
       const int pi = wave + 4 * k, i = i0 + pi;
       const bool row_real = pi < a.PH && (unsigned)i < (unsigned)hreal;     // wave-uniform
       const unsigned off = (row_real && col_real) ? (unsigned)i * (unsigned)rowstride + coloff : 0u;
-      u[k][0] = frame[off]; u[k][1] = frame[off + 1]; u[k][2] = frame[off + 2];
+      // one (unaligned) 4-byte load per pixel: its 3 bytes + 1 of the next; the very last
+      // pixel of the tensor reads the 4 bytes that end with it instead
+      const unsigned off4 = min(off, last_word);
+      u[k] = *reinterpret_cast<const unsigned*>(frame + off4) >> ((off - off4) * 8u);
     }
   };
   // zero padding of the frame, mean / scale, rounding; stores the patch into LDS
-  auto commit = [&](const Tile& t, const unsigned (&u)[kStemRows][3]) {
+  auto commit = [&](const Tile& t, const unsigned (&u)[kStemRows]) {
     const int i0 = t.oh0 * a.stride - a.pad_t, j0 = t.ow0 * a.stride - a.pad_l;
     const int j = j0 + lane;
     const bool col_in = (unsigned)j < (unsigned)a.W, col_real = (unsigned)j < (unsigned)wreal;
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
         float v[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          v[c] = fmaf((float)u[k][c], m_real, -a.mean[c]);    // exact: (u or 0) - mean
+          v[c] = fmaf((float)((u[k] >> (8 * c)) & 255u), m_real, -a.mean[c]);    // exact: (u or 0) - mean
           if (!a.unit_scale) v[c] *= a.scale[c];
           v[c] = inside ? v[c] : 0.f;
         }
@@ -180,7 +184,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
 
   // The next tile's bytes are fetched into registers before the current tile is computed,
   // so their latency hides behind its MFMAs and stores.
-  unsigned ureg[kStemRows][3];
+  unsigned ureg[kStemRows];
   Tile cur = decode(blockIdx.x);
   fetch(cur, ureg);
   for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
@@ -345,6 +349,7 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
   FSS_REQUIRE(n > 0 && hr > 0 && wr > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "bad shape");
   FSS_REQUIRE(sub >= 1 && sub <= 8, "sub must be in [1, 8]");
   FSS_REQUIRE(kh > 0 && kw > 0 && kh * kw <= 64, "filter must have at most 64 taps");
+  FSS_REQUIRE((long long)hr * wr * 3 >= 4, "frame too small");
   FSS_REQUIRE(cout > 0 && cout <= 64, "cout must be in [1, 64]");
   FSS_REQUIRE(stride > 0 && stride <= 4 && dilation > 0 && dilation <= 4, "bad stride / dilation");
   FSS_REQUIRE(pad_top >= 0 && pad_left >= 0, "negative padding");
