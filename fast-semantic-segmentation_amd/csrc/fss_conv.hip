@@ -29,6 +29,8 @@
 // 16-byte row-contiguous pieces (whole 128-byte lines per row segment), with an
 // output pixel stride so a branch can write into a channel slice of a concat
 // buffer.
+#include <type_traits>
+
 #include "fss_common.h"
 
 namespace fss {
@@ -331,16 +333,18 @@ conv_igemm_kernel(const ConvArgs a) {
   static_assert(WAVES_M * WAVES_N * SLABR * SROW * 4 <= NSTAGE * STAGE_BYTES,
                 "epilogue staging does not fit in the ring");
   static_assert(SLABR % FM == 0, "a staging slab must hold whole MFMA tiles");
-  constexpr int QPR = WTN / 4;               // float4 groups per staged row
-  constexpr int PASSES = SLABR * QPR / 64;   // float4 groups per lane per slab
+  constexpr int VW = 16 / (int)sizeof(TO);   // outputs per lane per pass: one 16-byte store
+  constexpr int QPR = WTN / VW;              // lane pieces per staged row
+  constexpr int PASSES = SLABR * QPR / 64;   // pieces per lane per slab
+  static_assert(SLABR * QPR % 64 == 0, "slab must split evenly over the lanes");
   constexpr int SLABS = WTM / SLABR;
   TO* __restrict__ yg = reinterpret_cast<TO*>(a.y);
   const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
   const int n_base = tile_n * BN + wn * WTN;
-  const bool vec_ok = ((a.y_ld & 3) == 0) && ((a.Cout & 3) == 0) &&
+  const bool vec_ok = ((a.y_ld & (VW - 1)) == 0) && ((a.Cout & (VW - 1)) == 0) &&
                       ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) &&
                       (rg == nullptr ||
-                       (((a.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.res) & 15) == 0)));
+                       (((a.res_ld & (VW - 1)) == 0) && ((reinterpret_cast<uintptr_t>(a.res) & 15) == 0)));
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
 
@@ -373,7 +377,9 @@ conv_igemm_kernel(const ConvArgs a) {
   // of the ring, the barrier and the staging of the first slab.  The loads are younger
   // than every DMA piece, so waiting for all but them drains the ring.
   constexpr bool RES_PREFETCH = sizeof(T) == 2;
-  uint2 rpre[RES_PREFETCH ? SLABS : 1][RES_PREFETCH ? PASSES : 1];
+  // VW bf16 residual values of one piece: 16 bytes (bf16 output) or 8 bytes (float output)
+  typedef typename std::conditional<VW == 8, uint4, uint2>::type rvec_t;
+  rvec_t rpre[RES_PREFETCH ? SLABS : 1][RES_PREFETCH ? PASSES : 1];
   bool drained = false;
   if constexpr (RES_PREFETCH) {
     if (rg != nullptr && vec_ok) {
@@ -382,10 +388,10 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
           const int gq = lane + p * 64;
-          const int m = tile_m * BM + wm * WTM + sl * SLABR + gq / QPR, n = n_base + (gq % QPR) * 4;
+          const int m = tile_m * BM + wm * WTM + sl * SLABR + gq / QPR, n = n_base + (gq % QPR) * VW;
           const bool ok = m < a.M && n < a.Cout;
           const T* rp = ok ? rg + (size_t)m * a.res_ld + n : reinterpret_cast<const T*>(g_zero_chunk);
-          rpre[sl][p] = *reinterpret_cast<const uint2*>(rp);
+          rpre[sl][p] = *reinterpret_cast<const rvec_t*>(rp);
         }
       wait_vmcnt<SLABS * PASSES>();
       drained = true;
@@ -393,7 +399,7 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int sl = 0; sl < SLABS; ++sl)
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) rpre[sl][p] = make_uint2(0u, 0u);
+        for (int p = 0; p < PASSES; ++p) rpre[sl][p] = rvec_t{};
     }
   }
   if (!drained) wait_vmcnt<0>();             // drain the zero-fill tail pieces
@@ -423,11 +429,15 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int g = lane + p * 64;
-      const int row = g / QPR, c4 = (g % QPR) * 4;
-      const int m = m_base + row, n = n_base + c4;
+      const int row = g / QPR, cv = (g % QPR) * VW;
+      const int m = m_base + row, n = n_base + cv;
       if (m < a.M && n < a.Cout) {
-        const float4 v4 = *reinterpret_cast<const float4*>(stage + row * SROW + c4);
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        float v[VW];
+#pragma unroll
+        for (int q = 0; q < VW; q += 4) {
+          const float4 v4 = *reinterpret_cast<const float4*>(stage + row * SROW + cv + q);
+          v[q] = v4.x; v[q + 1] = v4.y; v[q + 2] = v4.z; v[q + 3] = v4.w;
+        }
         TO* dst = yg + (size_t)m * a.y_ld + n;
         if (vec_ok) {
           if (rg != nullptr) {
@@ -435,24 +445,26 @@ conv_igemm_kernel(const ConvArgs a) {
               const float4 r4 = *reinterpret_cast<const float4*>(rg + (size_t)m * a.res_ld + n);
               v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             } else {
-              const uint2 r2 = rpre[sl][p];
-              v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-              v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+              const rvec_t rv = rpre[sl][p];
+              const unsigned* rw = reinterpret_cast<const unsigned*>(&rv);
+#pragma unroll
+              for (int q = 0; q < VW / 2; ++q) {
+                v[2 * q] += __uint_as_float(rw[q] << 16);
+                v[2 * q + 1] += __uint_as_float(rw[q] & 0xffff0000u);
+              }
             }
           }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
+          for (int e = 0; e < VW; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
           if constexpr (sizeof(TO) == 4) {
             *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
-            uint2 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(dst) = o;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                        pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < VW; ++e) {
             if (n + e < a.Cout) {
               float t = v[e];
               if (rg != nullptr) t += ElemTraits<T>::load(rg + (size_t)m * a.res_ld + n + e);

@@ -823,8 +823,8 @@ class CompiledGraph(object):
     def _assign_streams(self, release_after=None):
         """Puts the second chain that starts from the input frame (ICNet's full-resolution
         branch) on a side stream, with events where the chains exchange data.
-        release_after: index of a step of the main chain the side chain waits for before
-        it starts (None: starts with the main chain)."""
+        release_after (experiments only, see _setup_streams): index of a step of the main
+        chain the side chain waits for before it starts."""
         deps, main_src = self._dependencies()
         for s in self.steps:
             s.stream, s.waits, s.signal = 0, [], None
@@ -905,9 +905,12 @@ class CompiledGraph(object):
         return (time.perf_counter() - t0) / reps
 
     def _setup_streams(self, tune=True):
-        """Side-stream schedule; the step of the main chain after which the side chain
-        is released is picked by timing whole passes (memory-bound branch convolutions
-        overlap best with the MFMA-bound part of the backbone, wherever that is)."""
+        """Side-stream schedule.  The side chain forks from the plan's stream at the start of
+        the pass and nowhere else: a fork in the middle of the main chain (a captured node
+        with one successor on each stream) produced replays in which a later node of the
+        main chain ran before its predecessor had finished, so that shape is not offered.
+        The two-stream graph is kept only if it is faster than the single-stream one AND
+        its replays reproduce the eager single-stream outputs bit for bit."""
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.sh_side = ctypes.c_void_p(self.side_stream.cuda_stream)
         self.fork_event = ctypes.c_void_p()
@@ -915,32 +918,30 @@ class CompiledGraph(object):
         self.events.append(self.fork_event)
         if not self._assign_streams(None):
             return False
-        self.two_streams = True
         if not tune:
+            self.two_streams = True
             return True
-        side0 = min(i for i, s in enumerate(self.steps) if s.stream == 1)
-        main = [i for i, s in enumerate(self.steps) if s.stream == 0 and i < side0]
-        candidates = [None] + main[max(1, len(main) // 8) - 1::max(1, len(main) // 8)]
-        best, best_t = 'single', None
+        # reference: the eager single-stream pass that has just run (same input buffer)
+        self.sync()
+        outs = [self.vals[ln] for ln in self.out_nodes.values()]
+        ref = [v.buf.clone() for v in outs]
         self.two_streams = False
         self._capture()
-        best_t = single_t = self._time_launches()
-        for c in candidates:
-            self._assign_streams(c)
-            self.two_streams = True
-            self._capture()
-            t = self._time_launches()
-            if os.environ.get('FSS_PLAN_DEBUG'):
-                print('side stream released after step %s: %.3f ms (single stream %.3f ms)'
-                      % (c, t * 1e3, single_t * 1e3), flush=True)
-            if t < best_t:
-                best, best_t = c, t
-        if best == 'single':
-            self.two_streams = False
-        else:
-            self._assign_streams(best)
-            self.two_streams = True
-        self.release_after = best
+        single_t = self._time_launches()
+        self.two_streams = True
+        self._capture()
+        two_t = self._time_launches()
+        same = True
+        for _ in range(3):
+            self.launch()
+            self.sync()
+            same = same and all(torch.equal(v.buf.view(torch.uint8), r.view(torch.uint8))
+                                for v, r in zip(outs, ref))
+        if os.environ.get('FSS_PLAN_DEBUG'):
+            print('two streams: %.3f ms, single stream %.3f ms, replays identical: %s'
+                  % (two_t * 1e3, single_t * 1e3, same), flush=True)
+        self.two_streams = same and two_t < single_t
+        self.release_after = None if self.two_streams else 'single'
         return self.two_streams
 
     def launch(self):

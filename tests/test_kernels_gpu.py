@@ -180,6 +180,42 @@ def test_stem_conv_u8_matches_preprocess_resize_conv(case, dt):
     _close(got, ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'stem conv %s' % dt)
 
 
+AGREE_SHAPES = [
+    # n, h, w, cin, cout, k, stride, rate, residual
+    (2, 33, 65, 128, 256, 3, 1, 4, False),     # dilated, partial M tiles, taps skipped per block
+    (2, 33, 65, 64, 512, 3, 1, 16, False),     # d=16: most blocks skip taps, different per tile size
+    (1, 65, 129, 64, 256, 1, 1, 1, True),      # pointwise + residual
+    (3, 40, 52, 32, 72, 3, 2, 1, False),       # strided, cout not a multiple of the tiles
+    (1, 29, 31, 256, 264, 1, 1, 1, True),      # cout a multiple of 8 only: widest vector path edge
+]
+
+
+@pytest.mark.parametrize('shape', AGREE_SHAPES)
+def test_conv2d_bf16_configs_agree_bitwise_on_odd_shapes(shape):
+    """The plan's tuner may pick any configuration of one MFMA shape class for a layer:
+    they must all give the same bits, also when tiles are partial, when blocks of
+    different sizes skip different padding taps, and with a residual."""
+    gu, L = _gu(), _lib()
+    n, h, wd, cin, cout, k, stride, rate, has_res = shape
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))
+    x = gu.bf16_round(rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32))
+    w = gu.bf16_round(rng.normal(0, 0.05, (k, k, cin, cout)).astype(np.float32))
+    bias = rng.normal(0, 1, cout).astype(np.float32)
+    ho, pt, _ = O.same_padding(h, k, stride, rate)
+    wo, pl, _ = O.same_padding(wd, k, stride, rate)
+    res = gu.bf16_round(rng.normal(0, 1, (n, ho, wo, cout)).astype(np.float32)) if has_res else None
+    ref = O.conv2d(x, w, stride, rate, 'SAME', np.float64) + bias + (res if has_res else 0.0)
+    ref = O.relu(ref)
+    by_shape = {}
+    for cfg in range(1, L.lib.fss_conv_config_count() + 1):
+        out = gu.conv2d(x, w, bias, res, stride, rate, (pt, pl), (ho, wo), 'relu', 'bf16', config=cfg)
+        _close(out, ref, 1.0 / 128, 'conv config %d' % cfg)
+        info = (ctypes.c_int * 7)()
+        L.call('fss_conv_config_info', cfg, info)
+        first = by_shape.setdefault(info[6], out)
+        assert np.array_equal(out, first), 'config %d differs inside its shape class' % cfg
+
+
 def test_conv2d_rejects_bad_arguments():
     L = _lib()
     d = L.ConvDesc(n=1, h=8, w=8, cin=3, cout=8, kh=3, kw=3, stride=1, dilation=1, pad_top=1,
