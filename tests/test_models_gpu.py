@@ -267,3 +267,41 @@ def test_side_stream_and_stem_fusion_do_not_change_results(dtype):
     scale = float(np.abs(got['unfused'][0]).max())
     err = float(np.abs(got['two'][0] - got['unfused'][0]).max()) / scale
     assert err <= (1e-5 if dtype == 'float32' else 2e-2), err
+
+
+def test_every_launch_writes_only_its_own_outputs():
+    """Runs the launches of an ICNet plan one at a time and checks that no activation
+    buffer other than the launch's declared outputs changes (the two-stream schedule
+    derives its dependencies from exactly these read / write sets)."""
+    import ctypes
+    import torch
+    from fss import plan
+    from fss._lib import check
+    arch, ext, fs, pf, in_shape, pad_shape = CASES[0]
+    g, cfg, outs, weights = build(arch, ext, fs, pf, in_shape, pad_shape)
+    cg = plan.CompiledGraph(g, outs, weights, dtype='bfloat16', streams=1, use_hip_graph=False)
+    cg.run(np.random.default_rng(4).integers(0, 256, in_shape).astype(np.uint8))
+    bufs = {}
+    for v in list(cg.vals.values()) + [cg.input_val]:
+        bufs[v.buf.data_ptr()] = v.buf
+
+    def buf_of(ptr):
+        for bp, b in bufs.items():
+            if bp <= ptr < bp + b.numel() * b.element_size():
+                return bp
+        return None
+
+    for i, s in enumerate(cg.steps):
+        mine = set()
+        for ai in plan._OUT_ARGS[cg.step_fname[i]]:
+            a = s.args[ai]
+            for q in (list(a) if isinstance(a, ctypes.Array) else [a]):
+                if q:
+                    mine.add(buf_of(q))
+        assert None not in mine, 'output of %s is not a plan buffer' % s.name
+        before = {bp: b.clone() for bp, b in bufs.items() if bp not in mine}
+        check(s.fn(*s.args), s.name)
+        torch.cuda.synchronize()
+        for bp, b in before.items():
+            assert torch.equal(b.view(torch.uint8), bufs[bp].view(torch.uint8)), \
+                '%s (%s) wrote outside its outputs' % (s.name, s.kind)
