@@ -1,0 +1,479 @@
+// The first TWO convolutions of a full-resolution branch, fed straight from the
+// uint8 frame, in one kernel (gfx950, bf16).
+//
+// ICNet's high-resolution branch (architectures/icnet_architecture.py:213-226 in the
+// reference) starts with 3x3 stride-2 convolutions on the 1025x2049 frame.  The
+// output of the first one is the largest activation of the network (64 channels at
+// 513x1025); writing it and reading it back costs several times more HBM traffic than
+// everything else the two layers touch.  Here it only ever exists as a tile in LDS:
+//
+//   frame bytes --pad/mean/scale--> patch (LDS, 4 x bf16 per pixel)
+//       conv1 3x3/2 + bias + act  --> y1 tile (LDS, bf16, (2*TH2+1) x 33 pixels x C1)
+//       conv2 3x3/2 + bias + act  --> y (HBM), tile of TH2 x 16 output pixels
+//
+// Both convolutions run on the matrix cores as D[cout][pixel] = W[cout][k] * X[k][pixel]
+// (weights are the MFMA "A" operand, 16 adjacent pixels the "B" operand), so a lane
+// ends up with consecutive output channels of one pixel.  The second filter never
+// touches LDS: wave (ch, pp) owns 32 output channels and a share of the tile's rows, and
+// keeps its 9 * C1/32 * 2 weight fragments in registers for the whole (persistent) block.
+// The k order of both convolutions is the one the stand-alone kernels use (tap-major,
+// channels inside a tap), and y1 is rounded to bf16 exactly where the unfused path
+// stores it, so the result equals running the two layers one after the other.
+//
+// y1 tile layout: pixel (i, j) lives at pixel slot i*33 + (j&1)*17 + (j>>1) (columns
+// split by parity: a stride-2 tap reads 16 consecutive slots) and its 16-byte chunk c
+// is stored at chunk c ^ f(j>>1), which spreads the 16 lanes of every ds_read_b128
+// service group over all banks.
+#include <algorithm>
+
+#include "fss_common.h"
+
+namespace fss {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+struct Stem2Args {
+  const uint8_t* x;
+  const void* w1;
+  const float* b1;
+  const void* w2;
+  const float* b2;
+  void* y;
+  int N, Hr, Wr, sub, H, W;
+  int pad_t1, pad_l1, H1, W1, act1;
+  int pad_t2, pad_l2, H2, W2, act2;
+  int w2_kpad, y_ld;
+  int tiles_x, tiles_y, total_tiles, unit_scale;
+  float mean[3], scale[3];
+};
+
+constexpr int kS2TW = 16;                  // output columns of a tile (one MFMA pixel group per row)
+constexpr int kS2Y1W = 2 * kS2TW + 1;      // y1 columns of a tile
+constexpr int kS2Even = kS2TW + 1;         // even y1 columns of a tile (stored first in a row)
+constexpr int kS2PW = 2 * kS2Y1W + 1;      // patch columns
+constexpr int kS2K4 = 64;                  // conv1 K: 9 taps x 4 channels, padded to two MFMA steps
+constexpr int kS2WRow = kS2K4 * 2 + 16;    // LDS bytes per conv1 weight row (+16: distinct banks)
+
+// KS1 = C1 / 32, CW = C2 / 32, TH2 = output rows per tile, NW = waves per block
+template <int KS1, int CW, int TH2, int NW>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
+stem2_conv_kernel(const Stem2Args a) {
+  constexpr int NT = NW * 64;
+  constexpr int R1 = 2 * TH2 + 1;            // y1 rows of a tile
+  constexpr int PH = 2 * R1 + 1;             // patch rows
+  constexpr int PP = PH * kS2PW;             // patch pixels
+  constexpr int FS = (PP + NT - 1) / NT;     // patch pixels per thread
+  constexpr int NJ1 = 2 * KS1;               // 16-channel groups of conv1
+  constexpr int PXB = 64 * KS1;              // bytes of one y1 pixel
+  constexpr int CPP = PXB / 16;              // chunks per y1 pixel (4 or 8)
+  constexpr int Y1PIX = R1 * kS2Y1W;
+  constexpr int G1 = (Y1PIX + 15) / 16;      // conv1 pixel groups of a tile
+  constexpr int GS = NW / KS1;                // waves that share conv1's pixel groups
+  constexpr int G1W = (G1 + GS - 1) / GS;    // ... groups per wave
+  constexpr int PGW = TH2 * CW / NW;         // output rows per wave
+  static_assert(TH2 * CW % NW == 0 && PGW >= 1, "rows must split evenly over the waves");
+  static_assert(KS1 == 1 || KS1 == 2, "C1 must be 32 or 64");
+
+  constexpr int OFF_B1 = 0, OFF_B2 = 256, OFF_W1 = 512;
+  constexpr int OFF_PATCH = OFF_W1 + NJ1 * 16 * kS2WRow;
+  constexpr int OFF_Y1 = (OFF_PATCH + PP * 8 + 255) / 256 * 256;
+
+  extern __shared__ __attribute__((aligned(256))) char smem[];
+  float* lb1 = reinterpret_cast<float*>(smem + OFF_B1);
+  float* lb2 = reinterpret_cast<float*>(smem + OFF_B2);
+  char* wl = smem + OFF_W1;
+  char* patch = smem + OFF_PATCH;
+  char* y1 = smem + OFF_Y1;
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int p = lane & 15, g = lane >> 4;
+  auto swz = [](int hc) { return CPP == 8 ? ((hc >> 1) & 7) : ((hc >> 2) & 3); };
+
+  // ---- per-block tables
+  if (tid < 64) {
+    lb1[tid] = tid < 32 * KS1 ? a.b1[tid] : 0.f;
+    lb2[tid] = tid < 32 * CW ? a.b2[tid] : 0.f;
+  }
+  {  // conv1 weights, one padded row per output channel
+    constexpr int cpr = kS2K4 * 2 / 16;
+    for (int idx = tid; idx < 32 * KS1 * cpr; idx += NT) {
+      const int co = idx / cpr, c = idx - co * cpr;
+      *reinterpret_cast<uint4*>(wl + co * kS2WRow + c * 16) = *reinterpret_cast<const uint4*>(
+          reinterpret_cast<const char*>(a.w1) + ((size_t)co * kS2K4 * 2 + c * 16));
+    }
+  }
+
+  // ---- conv2 weights: this wave's 32 output channels, in registers for good.
+  // A-row r of tile nj is channel 32*ch + 8*(r>>2) + 4*nj + (r&3): lane group g then holds
+  // the 8 consecutive channels 32*ch + 8*g .. +7 of its pixel.
+  const int ch = wave % CW, pp = wave / CW;
+  uint4 w2f[9][KS1][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int kh = 0; kh < KS1; ++kh)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) {
+        const int co = 32 * ch + 8 * (p >> 2) + 4 * nj + (p & 3);
+        w2f[t][kh][nj] = *reinterpret_cast<const uint4*>(
+            reinterpret_cast<const bf16_t*>(a.w2) + (size_t)co * a.w2_kpad + t * (32 * KS1) + kh * 32 + 8 * g);
+      }
+
+  // ---- conv1: wave (c1h, gs) makes 32 channels (c1h) of the pixel groups gs, gs + GS, ...;
+  // lane (p, g) of group grp is pixel 16*grp + p of the y1 tile, channels 32*c1h + 8*g .. +7
+  const int c1h = wave % KS1, gs = wave / KS1;
+  // patch offsets of this lane group's conv1 taps: k step 0 holds taps 2g, 2g+1; step 1 tap 8
+  // (lane group 0) and zero weights (they read pixel 0 of the group: any finite value)
+  const int t0 = 2 * g, t1 = 2 * g + 1;
+  const int to00 = (t0 / 3) * kS2PW + t0 % 3, to01 = (t1 / 3) * kS2PW + t1 % 3;
+  const int to10 = g == 0 ? 2 * kS2PW + 2 : 0;
+
+  // ---- conv2 read offsets of this lane: pixel slot p + e (e = tap column >> 1), chunk 4*kh + g
+  int roff[2][KS1];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int kh = 0; kh < KS1; ++kh) roff[e][kh] = (p + e) * PXB + (((4 * kh + g) ^ swz(p + e)) & (CPP - 1)) * 16;
+
+  const float lo1 = a.act1 == FSS_ACT_NONE ? -INFINITY : 0.f, hi1 = a.act1 == FSS_ACT_RELU6 ? 6.f : INFINITY;
+  const float lo2 = a.act2 == FSS_ACT_NONE ? -INFINITY : 0.f, hi2 = a.act2 == FSS_ACT_RELU6 ? 6.f : INFINITY;
+
+  // patch pixel tid + NT*k of this thread -> (row, column), -1 past the end
+  auto patch_rc = [&](int k, int& pi, int& pj) {
+    const int idx = tid + NT * k;
+    pi = idx / kS2PW;
+    pj = idx - pi * kS2PW;
+    return idx < PP;
+  };
+  const int rowstride = a.sub * a.Wr * 3, colstride = a.sub * 3;
+  const int hreal = min(a.H, (a.Hr + a.sub - 1) / a.sub), wreal = min(a.W, (a.Wr + a.sub - 1) / a.sub);
+
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  struct Tile { int n, ty, tx; };
+  auto decode = [&](int tile) {
+    Tile t;
+    t.n = tile / tiles_per_img;
+    const int rem = tile - t.n * tiles_per_img;
+    t.ty = rem / a.tiles_x;
+    t.tx = rem - t.ty * a.tiles_x;
+    return t;
+  };
+  const Tile step = decode(gridDim.x);
+  auto advance = [&](Tile t) {
+    t.tx += step.tx;
+    if (t.tx >= a.tiles_x) { t.tx -= a.tiles_x; ++t.ty; }
+    t.ty += step.ty;
+    if (t.ty >= a.tiles_y) { t.ty -= a.tiles_y; ++t.n; }
+    t.n += step.n;
+    return t;
+  };
+  // first y1 row / column of a tile, first input row / column of its patch
+  auto y1_i0 = [&](const Tile& t) { return t.ty * TH2 * 2 - a.pad_t2; };
+  auto y1_j0 = [&](const Tile& t) { return t.tx * kS2TW * 2 - a.pad_l2; };
+
+  // A tile whose whole patch lies on frame pixels (and not on the last pixel of a row, so
+  // that 4-byte loads stay inside the tensor) needs no masks; so does a tile whose y1 rows
+  // and columns all exist.  Both tests are block-uniform.
+  auto patch_interior = [&](const Tile& t) {
+    const int i0 = y1_i0(t) * 2 - a.pad_t1, j0 = y1_j0(t) * 2 - a.pad_l1;
+    return i0 >= 0 && j0 >= 0 && i0 + PH <= hreal && j0 + kS2PW < wreal;
+  };
+  // Frame bytes of the patch.  Branch-free: slots that are not frame pixels read byte 0 of
+  // the frame and are replaced at commit, so every load is in flight before any is used.
+  auto fetch = [&](const Tile& t, unsigned (&u)[FS]) {
+    const int i0 = y1_i0(t) * 2 - a.pad_t1, j0 = y1_j0(t) * 2 - a.pad_l1;
+    const uint8_t* frame = a.x + (size_t)t.n * a.Hr * a.Wr * 3;
+    if (patch_interior(t)) {
+      const uint8_t* base = frame + (size_t)i0 * rowstride + (size_t)j0 * colstride;
+#pragma unroll
+      for (int k = 0; k < FS; ++k) {
+        int pi, pj;
+        const bool slot = patch_rc(k, pi, pj);
+        const unsigned off = slot ? (unsigned)pi * (unsigned)rowstride + (unsigned)pj * (unsigned)colstride : 0u;
+        u[k] = *reinterpret_cast<const unsigned*>(base + off);
+      }
+      return;
+    }
+    const unsigned last_word = t.n == a.N - 1 ? (unsigned)(a.Hr * a.Wr * 3 - 4) : 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < FS; ++k) {
+      int pi, pj;
+      const bool slot = patch_rc(k, pi, pj);
+      const int i = i0 + pi, j = j0 + pj;
+      const bool real = slot && (unsigned)i < (unsigned)hreal && (unsigned)j < (unsigned)wreal;
+      const unsigned off = real ? (unsigned)i * (unsigned)rowstride + (unsigned)j * (unsigned)colstride : 0u;
+      // one (unaligned) 4-byte load per pixel: its 3 bytes + 1 of the next; the very last
+      // pixel of the tensor reads the 4 bytes that end with it instead
+      const unsigned off4 = min(off, last_word);
+      u[k] = *reinterpret_cast<const unsigned*>(frame + off4) >> ((off - off4) * 8u);
+    }
+  };
+  // zero fill of the bounding box, mean / scale, zero padding of conv1, rounding
+  auto commit = [&](const Tile& t, const unsigned (&u)[FS]) {
+    const int i0 = y1_i0(t) * 2 - a.pad_t1, j0 = y1_j0(t) * 2 - a.pad_l1;
+    const bool interior = patch_interior(t);
+#pragma unroll
+    for (int k = 0; k < FS; ++k) {
+      int pi, pj;
+      const bool slot = patch_rc(k, pi, pj);
+      float v[3];
+      if (interior) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          v[c] = (float)((u[k] >> (8 * c)) & 255u) - a.mean[c];
+          if (!a.unit_scale) v[c] *= a.scale[c];
+        }
+      } else {
+        const int i = i0 + pi, j = j0 + pj;
+        const bool real = (unsigned)i < (unsigned)hreal && (unsigned)j < (unsigned)wreal;
+        const bool inside = (unsigned)i < (unsigned)a.H && (unsigned)j < (unsigned)a.W;
+        const float m_real = real ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          v[c] = fmaf((float)((u[k] >> (8 * c)) & 255u), m_real, -a.mean[c]);    // exact: (u or 0) - mean
+          if (!a.unit_scale) v[c] *= a.scale[c];
+          v[c] = inside ? v[c] : 0.f;
+        }
+      }
+      if (slot) {
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], 0.f);
+        *reinterpret_cast<uint2*>(patch + (size_t)(tid + NT * k) * 8) = o;
+      }
+    }
+  };
+
+  unsigned ureg[FS];
+  Tile cur = decode(blockIdx.x);
+  fetch(cur, ureg);
+  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
+    // every wave is past the previous tile's conv1 (barrier below), so the patch is free
+    commit(cur, ureg);
+    __syncthreads();   // patch complete (first pass: LDS tables too); previous conv2 reads of y1 done
+    const Tile now = cur;
+    // past the last tile this re-reads the current one: harmless, and keeps the loop branch-free
+    if (tile + (int)gridDim.x < a.total_tiles) cur = advance(cur);
+
+    // ---------------- conv1: patch -> y1 tile
+    {
+      uint4 w1f[2][2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+          w1f[st][nj] = *reinterpret_cast<const uint4*>(
+              wl + (32 * c1h + 8 * (p >> 2) + 4 * nj + (p & 3)) * kS2WRow + (32 * st + 8 * g) * 2);
+      const float4 bb0 = *reinterpret_cast<const float4*>(lb1 + 32 * c1h + 8 * g);
+      const float4 bb1 = *reinterpret_cast<const float4*>(lb1 + 32 * c1h + 8 * g + 4);
+      const int i1_0 = y1_i0(now), j1_0 = y1_j0(now);
+      // pixels of the tile that lie outside conv1's output are conv2's zero padding
+      const bool y1_interior = i1_0 >= 0 && j1_0 >= 0 && i1_0 + R1 <= a.H1 && j1_0 + kS2Y1W <= a.W1;
+      // pixel (i, j) of this lane in group gs + GS*t, advanced by 16*GS pixels per step
+      constexpr int STEP_I = 16 * GS / kS2Y1W, STEP_J = 16 * GS % kS2Y1W;
+      int i = (16 * gs + p) / kS2Y1W, j = (16 * gs + p) % kS2Y1W;
+      // the B operands (patch pixels of this lane's taps) of a group: k step 0 = b[0], b[1],
+      // k step 1 = b[2], b[3]
+      auto load_b = [&](int ii, int jj, uint2 (&b)[4]) {
+        const char* src = patch + (size_t)((2 * ii) * kS2PW + 2 * jj) * 8;
+        b[0] = *reinterpret_cast<const uint2*>(src + to00 * 8);
+        b[1] = *reinterpret_cast<const uint2*>(src + to01 * 8);
+        b[2] = *reinterpret_cast<const uint2*>(src + to10 * 8);
+        b[3] = *reinterpret_cast<const uint2*>(src);
+      };
+      uint2 bq[4];
+      load_b(min(i, R1 - 1), j, bq);
+#pragma unroll 2
+      for (int t = 0; t < G1W; ++t) {
+        if (16 * (gs + GS * t) >= Y1PIX) break;                    // wave-uniform
+        const int ci = i, cj = j;
+        uint2 bc[4] = {bq[0], bq[1], bq[2], bq[3]};
+        j += STEP_J;
+        i += STEP_I;
+        if (j >= kS2Y1W) { j -= kS2Y1W; ++i; }
+        load_b(min(i, R1 - 1), j, bq);      // next group's operands (clamped past the tile: unused)
+        f32x4 acc[2];
+        acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const uint4 b = make_uint4(bc[2 * st].x, bc[2 * st].y, bc[2 * st + 1].x, bc[2 * st + 1].y);
+#pragma unroll
+          for (int nj = 0; nj < 2; ++nj)
+            acc[nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1f[st][nj]),
+                                                              __builtin_bit_cast(bf16x8_t, b), acc[nj], 0, 0, 0);
+        }
+        float v[8] = {acc[0][0] + bb0.x, acc[0][1] + bb0.y, acc[0][2] + bb0.z, acc[0][3] + bb0.w,
+                      acc[1][0] + bb1.x, acc[1][1] + bb1.y, acc[1][2] + bb1.z, acc[1][3] + bb1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_amdgcn_fmed3f(v[q], lo1, hi1);
+        uint4 o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                             pack_bf16x2(v[6], v[7]));
+        if (!y1_interior) {
+          const bool inside = (unsigned)(i1_0 + ci) < (unsigned)a.H1 && (unsigned)(j1_0 + cj) < (unsigned)a.W1;
+          const unsigned m = inside ? 0xffffffffu : 0u;
+          o.x &= m; o.y &= m; o.z &= m; o.w &= m;
+        }
+        if (ci < R1) {
+          const int hc = cj >> 1;
+          char* dst = y1 + (ci * kS2Y1W + (cj & 1) * kS2Even + hc) * PXB + ((4 * c1h + g) ^ swz(hc)) * 16;
+          *reinterpret_cast<uint4*>(dst) = o;
+        }
+      }
+    }
+    __syncthreads();   // y1 tile complete; every wave is done with the patch
+    // the next tile's bytes are in flight during conv2 and the stores
+    fetch(cur, ureg);
+
+    // ---------------- conv2: y1 tile -> output
+    f32x4 acc2[PGW][2];
+#pragma unroll
+    for (int t = 0; t < PGW; ++t)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) acc2[t][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* rowp = y1 + (size_t)(2 * pp * PGW) * (kS2Y1W * PXB);
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int kh = 0; kh < KS1; ++kh)
+#pragma unroll
+          for (int t = 0; t < PGW; ++t) {
+            const uint4 b = *reinterpret_cast<const uint4*>(
+                rowp + ((2 * t + r) * kS2Y1W + (s & 1) * kS2Even) * PXB + roff[s >> 1][kh]);
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj)
+              acc2[t][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8_t, w2f[r * 3 + s][kh][nj]), __builtin_bit_cast(bf16x8_t, b),
+                  acc2[t][nj], 0, 0, 0);
+          }
+    // lane (p, g): channels 32*ch + 8*g .. +7 of pixel (row, p)
+    const int ow = now.tx * kS2TW + p;
+    const float4 c0 = *reinterpret_cast<const float4*>(lb2 + 32 * ch + 8 * g);
+    const float4 c1 = *reinterpret_cast<const float4*>(lb2 + 32 * ch + 8 * g + 4);
+#pragma unroll
+    for (int t = 0; t < PGW; ++t) {
+      const int oh = now.ty * TH2 + pp * PGW + t;
+      if (oh < a.H2 && ow < a.W2) {
+        const float v[8] = {acc2[t][0][0] + c0.x, acc2[t][0][1] + c0.y, acc2[t][0][2] + c0.z, acc2[t][0][3] + c0.w,
+                            acc2[t][1][0] + c1.x, acc2[t][1][1] + c1.y, acc2[t][1][2] + c1.z, acc2[t][1][3] + c1.w};
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_bf16x2(__builtin_amdgcn_fmed3f(v[2 * e], lo2, hi2),
+                             __builtin_amdgcn_fmed3f(v[2 * e + 1], lo2, hi2));
+        bf16_t* dst = reinterpret_cast<bf16_t*>(a.y) +
+                      (((size_t)now.n * a.H2 + oh) * a.W2 + ow) * a.y_ld + 32 * ch + 8 * g;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
+template <int KS1, int CW, int TH2, int NW>
+static int launch_stem2(const Stem2Args& a0, hipStream_t stream) {
+  Stem2Args a = a0;
+  constexpr int R1 = 2 * TH2 + 1, PH = 2 * R1 + 1, PP = PH * kS2PW;
+  constexpr size_t off_patch = 512 + (size_t)(2 * KS1) * 16 * kS2WRow;
+  constexpr size_t off_y1 = (off_patch + (size_t)PP * 8 + 255) / 256 * 256;
+  constexpr size_t smem = off_y1 + (size_t)R1 * kS2Y1W * 64 * KS1;
+  static_assert(smem <= 160 * 1024, "tile too large for LDS");
+  a.tiles_x = ceil_div(a.W2, kS2TW);
+  a.tiles_y = ceil_div(a.H2, TH2);
+  const long long total = (long long)a.tiles_x * a.tiles_y * a.N;
+  if (total <= 0 || total >= 0x7fffffffLL) {
+    set_error("fss_stem2_conv_u8: too many tiles");
+    return 2;
+  }
+  a.total_tiles = (int)total;
+  auto kern = stem2_conv_kernel<KS1, CW, TH2, NW>;
+  static bool attr_set = false;   // per instantiation
+  if (smem > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+      set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+      return 1;
+    }
+    attr_set = true;
+  }
+  // persistent blocks: as many as are resident on the chip at once, at most one per tile
+  static int per_cu = 0, num_cu = 0;
+  if (num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      set_error("fss_stem2_conv_u8: cannot query the device");
+      return 1;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NW * 64,
+                                                     smem) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    num_cu = prop.multiProcessorCount;
+  }
+  const int blocks = std::min(a.total_tiles, num_cu * per_cu);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), smem, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(std::string("fss_stem2_conv_u8 launch: ") + hipGetErrorString(e));
+    return 3;
+  }
+  return 0;
+}
+
+}  // namespace fss
+
+using namespace fss;
+
+extern "C" int fss_stem2_conv_u8(const uint8_t* x, const void* w1_packed, const float* bias1,
+                                 const void* w2_packed, const float* bias2, void* y, int n, int hr,
+                                 int wr, int sub, int h, int w, const float* mean3, const float* scale3,
+                                 int c1, int pad_top1, int pad_left1, int h1, int w1, int act1, int c2,
+                                 int pad_top2, int pad_left2, int h2, int w2, int act2, int dtype,
+                                 int y_ld, void* stream) {
+  FSS_REQUIRE(x && w1_packed && bias1 && w2_packed && bias2 && y && mean3 && scale3, "null argument");
+  FSS_REQUIRE(dtype == FSS_BF16, "only bfloat16 is supported");
+  FSS_REQUIRE(n > 0 && hr > 0 && wr > 0 && h > 0 && w > 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0, "bad shape");
+  FSS_REQUIRE(sub >= 1 && sub <= 8, "sub must be in [1, 8]");
+  FSS_REQUIRE((long long)hr * wr * 3 >= 4, "frame too small");
+  FSS_REQUIRE(c1 == 32 || c1 == 64, "c1 must be 32 or 64");
+  FSS_REQUIRE(c2 == 32 || c2 == 64, "c2 must be 32 or 64");
+  FSS_REQUIRE(pad_top1 >= 0 && pad_left1 >= 0 && pad_top2 >= 0 && pad_left2 >= 0 && pad_top1 <= 2 &&
+                  pad_left1 <= 2 && pad_top2 <= 2 && pad_left2 <= 2, "padding must be in [0, 2]");
+  for (int act : {act1, act2})
+    FSS_REQUIRE(act == FSS_ACT_NONE || act == FSS_ACT_RELU || act == FSS_ACT_RELU6, "bad act");
+  FSS_REQUIRE(y_ld >= c2 && y_ld % 8 == 0, "y_ld must be a multiple of 8 and at least c2");
+  // both layers: 3x3, stride 2; every output pixel's first tap starts inside the padded input
+  FSS_REQUIRE((long long)(h1 - 1) * 2 - pad_top1 < h && (long long)(w1 - 1) * 2 - pad_left1 < w,
+              "first output size exceeds the input");
+  FSS_REQUIRE((long long)(h2 - 1) * 2 - pad_top2 < h1 && (long long)(w2 - 1) * 2 - pad_left2 < w1,
+              "second output size exceeds the first");
+  FSS_REQUIRE(((uintptr_t)w1_packed & 15) == 0 && ((uintptr_t)w2_packed & 15) == 0 && ((uintptr_t)y & 15) == 0,
+              "unaligned pointer");
+  FSS_REQUIRE((long long)hr * wr * 3 < 0x7fffffffLL && (long long)sub * wr * 3 < (1 << 24) && hr < (1 << 24),
+              "frame too large");
+  Stem2Args a;
+  a.x = x; a.w1 = w1_packed; a.b1 = bias1; a.w2 = w2_packed; a.b2 = bias2; a.y = y;
+  a.N = n; a.Hr = hr; a.Wr = wr; a.sub = sub; a.H = h; a.W = w;
+  a.pad_t1 = pad_top1; a.pad_l1 = pad_left1; a.H1 = h1; a.W1 = w1; a.act1 = act1;
+  a.pad_t2 = pad_top2; a.pad_l2 = pad_left2; a.H2 = h2; a.W2 = w2; a.act2 = act2;
+  int k_pad = 0, cout_pad = 0;
+  if (fss_stem_pack_dims(3, 3, c1, dtype, &k_pad, &cout_pad)) return 2;
+  FSS_REQUIRE(k_pad == kS2K4 && cout_pad == c1, "unexpected first-layer packing");
+  if (fss_conv_pack_dims(c1, 3, 3, c2, dtype, &k_pad, &cout_pad)) return 2;
+  a.w2_kpad = k_pad;
+  a.y_ld = y_ld;
+  a.tiles_x = a.tiles_y = a.total_tiles = 0;
+  for (int i = 0; i < 3; ++i) { a.mean[i] = mean3[i]; a.scale[i] = scale3[i]; }
+  a.unit_scale = scale3[0] == 1.f && scale3[1] == 1.f && scale3[2] == 1.f;
+  hipStream_t s = (hipStream_t)stream;
+  // tiles of 4 x 16 output pixels, 4 waves: two blocks share a CU
+  switch ((c1 / 32) * 10 + c2 / 32) {
+    case 11: return launch_stem2<1, 1, 4, 4>(a, s);
+    case 12: return launch_stem2<1, 2, 4, 4>(a, s);
+    case 21: return launch_stem2<2, 1, 4, 4>(a, s);
+    default: return launch_stem2<2, 2, 4, 4>(a, s);
+  }
+}

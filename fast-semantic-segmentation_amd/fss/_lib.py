@@ -60,6 +60,7 @@ PROTOTYPES = {
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     'fss_stem_pack_dims': (c_int, [c_int, c_int, c_int, c_int, c_int_p, c_int_p]),
     'fss_stem_conv_u8': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float_p, c_float_p] + [c_int] * 12 + [c_void_p]),
+    'fss_stem2_conv_u8': (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_float_p, c_float_p] + [c_int] * 14 + [c_void_p]),
     'fss_dwconv2d_nhwc': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 14 + [c_void_p]),
     'fss_maxpool_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     'fss_subsample_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),

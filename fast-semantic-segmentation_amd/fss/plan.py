@@ -91,7 +91,7 @@ class Step(object):
 # index of the output-pointer arguments of every kernel entry point (everything else
 # that points into an activation buffer is read)
 _OUT_ARGS = {
-    'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_conv2d_nhwc': (5,),
+    'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
     'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1,), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
     'fss_add_act': (2,), 'fss_copy_channels': (2,), 'fss_upsample_argmax': (1, 2),
@@ -108,7 +108,7 @@ class CompiledGraph(object):
 
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
-                 fuse_stem=True, streams=2, fuse_pyramid_pool=True):
+                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
@@ -131,9 +131,11 @@ class CompiledGraph(object):
             raise ValueError('mfma_edge must be 16 or 32')
         self.fuse_stem = fuse_stem
         self.fuse_pyramid_pool = fuse_pyramid_pool
+        self.fuse_stem2 = fuse_stem2
         self.two_streams = False
         self.release_after = None
         self.events = []
+        self.retired_graphs = []
         self.tuned_now = 0      # layer shapes timed by this plan (0: all came from the table)
         with torch.cuda.device(self.device):
             self._import(graph, outputs, commute_classifier)
@@ -367,16 +369,61 @@ class CompiledGraph(object):
         self.keepalive.append(wdev)
         bdev = self._dev_f32(bias)
         self.param_bytes += cout * kh * kw * 3 * _ESZ[self.dt]
-        out = Val(self._alloc(ln.shape, self.dt), ln.shape, self.dt)
-        self.vals[ln] = out
         mean = (ctypes.c_float * 3)(*pre.attrs['mean'])
         sc = (ctypes.c_float * 3)(*pre.attrs['scale'])
+        nxt = self._stem2_partner(ln)
+        if nxt is not None:
+            return self._l_stem2_conv(ln, nxt, x, sub, h, w, wdev, bdev, mean, sc)
+        out = Val(self._alloc(ln.shape, self.dt), ln.shape, self.dt)
+        self.vals[ln] = out
         self._emit('stem', a['weights'].rsplit('/', 1)[0], 'fss_stem_conv_u8',
                    (x.ptr, wdev.data_ptr(), bdev.data_ptr(), out.ptr, n, hr, wr, sub, h, w, mean, sc,
                     cout, kh, kw, a['stride'], a['rate'], a['pad_top'], a['pad_left'], ho, wo,
                     _lib.ACT_CODES[a['activation']], _CODE[self.dt], out.ld, self.sh),
                    flops=2 * n * ho * wo * cout * kh * kw * 3,
                    nbytes=n * (hr // sub) * (wr // sub) * 3 + n * ho * wo * cout * _ESZ[self.dt],
+                   keep=(mean, sc))
+
+    def _stem2_partner(self, ln):
+        """The convolution that consumes stem conv `ln` when both can run as one
+        fss_stem2_conv_u8 launch (3x3, stride 2, batch norm, 32 or 64 channels, bfloat16),
+        so that the output of `ln` never reaches memory."""
+        def shape_ok(c):
+            a = c.attrs
+            return ((a['kh'], a['kw'], a['stride'], a['rate']) == (3, 3, 2, 1) and a['biases'] is None
+                    and c.shape[3] in (32, 64) and a['pad_top'] <= 2 and a['pad_left'] <= 2)
+        if not self.fuse_stem2 or self.dt != 'bf16' or not shape_ok(ln):
+            return None
+        nxt = self._only_consumer(ln, 'conv2d')
+        if nxt is None or not shape_ok(nxt) or self._only_consumer(nxt, 'add') is not None:
+            return None
+        return nxt
+
+    def _l_stem2_conv(self, ln, nxt, x, sub, h, w, w1dev, b1dev, mean, sc):
+        a1, a2 = ln.attrs, nxt.attrs
+        n, hr, wr, _ = x.shape
+        _, h1, w1, c1 = ln.shape
+        _, h2, w2, c2 = nxt.shape
+        scale, bias = self._fold_bn(a2, c2)
+        Wt = self.weights[a2['weights']].astype(np.float64) * scale      # [3,3,c1,c2]
+        k_pad, cout_pad = _lib.conv_pack_dims(c1, 3, 3, c2, _CODE[self.dt])
+        Wp = np.zeros((cout_pad, k_pad), np.float32)
+        Wp[:c2, :9 * c1] = Wt.transpose(3, 0, 1, 2).reshape(c2, -1)
+        w2dev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+        self.keepalive.append(w2dev)
+        b2dev = self._dev_f32(bias)
+        self.param_bytes += c2 * 9 * c1 * _ESZ[self.dt]
+        out = Val(self._alloc(nxt.shape, self.dt), nxt.shape, self.dt)
+        self.vals[nxt] = out
+        self.fused.add(nxt)
+        self._emit('stem2', a2['weights'].rsplit('/', 1)[0], 'fss_stem2_conv_u8',
+                   (x.ptr, w1dev.data_ptr(), b1dev.data_ptr(), w2dev.data_ptr(), b2dev.data_ptr(), out.ptr,
+                    n, hr, wr, sub, h, w, mean, sc,
+                    c1, a1['pad_top'], a1['pad_left'], h1, w1, _lib.ACT_CODES[a1['activation']],
+                    c2, a2['pad_top'], a2['pad_left'], h2, w2, _lib.ACT_CODES[a2['activation']],
+                    _CODE[self.dt], out.ld, self.sh),
+                   flops=2 * n * (h1 * w1 * c1 * 27 + h2 * w2 * c2 * 9 * c1),
+                   nbytes=n * (hr // sub) * (wr // sub) * 3 + n * h2 * w2 * c2 * _ESZ[self.dt],
                    keep=(mean, sc))
 
     def _l_conv(self, ln):
@@ -884,7 +931,10 @@ class CompiledGraph(object):
 
     def _capture(self):
         if self.graph_exec is not None:
-            lib.fss_graph_destroy(self.graph_exec)
+            # destroyed with the plan, not here: tearing an executable graph down right after
+            # its last launch has completed and launching a new one next was seen to crash
+            # inside the HIP runtime now and then
+            self.retired_graphs.append(self.graph_exec)
             self.graph_exec = None
         _lib.call('fss_capture_begin', self.sh)
         ex = ctypes.c_void_p()
@@ -990,8 +1040,10 @@ class CompiledGraph(object):
 
     def __del__(self):
         try:
-            if self.graph_exec is not None:
-                lib.fss_graph_destroy(self.graph_exec)
+            lib.fss_device_sync()
+            for g in self.retired_graphs + [self.graph_exec]:
+                if g is not None:
+                    lib.fss_graph_destroy(g)
             for e in self.events:
                 lib.fss_event_destroy(e)
         except Exception:

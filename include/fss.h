@@ -213,6 +213,25 @@ int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const float* bias, 
                      int stride, int dilation, int pad_top, int pad_left, int ho, int wo,
                      int act, int dtype, int y_ld, void* stream);
 
+/* The first TWO convolutions of a branch in one kernel, from the uint8 frame:
+ *   y1 = act1(conv3x3/2(img, W1; pad_top1/pad_left1) + bias1)   [n,h1,w1,c1], rounded to `dtype`
+ *   y  = act2(conv3x3/2(y1,  W2; pad_top2/pad_left2) + bias2)   [n,h2,w2,c2], pixel stride y_ld
+ * with img as in fss_stem_conv_u8.  y1 never reaches memory: it is the largest
+ * activation of ICNet (64 channels at 513 x 1025), and the result equals
+ * fss_stem_conv_u8 followed by fss_conv2d_nhwc.  Replaces the first two
+ * slim.conv2d + batch norm + activation of the full-resolution branch
+ * (architectures/icnet_architecture.py:213-226 'Conv', 'Conv_1') together with the
+ * preprocessing listed at fss_stem_conv_u8.  W1 packed as for fss_stem_conv_u8
+ * (fss_stem_pack_dims(3, 3, c1)), W2 as for fss_conv2d_nhwc
+ * (fss_conv_pack_dims(c1, 3, 3, c2)).  Limits: dtype bf16, c1 and c2 in {32, 64},
+ * paddings <= 2, y_ld a multiple of 8. */
+int fss_stem2_conv_u8(const uint8_t* x, const void* w1_packed, const float* bias1,
+                      const void* w2_packed, const float* bias2, void* y, int n, int hr,
+                      int wr, int sub, int h, int w, const float* mean3, const float* scale3,
+                      int c1, int pad_top1, int pad_left1, int h1, int w1, int act1, int c2,
+                      int pad_top2, int pad_left2, int h2, int w2, int act2, int dtype,
+                      int y_ld, void* stream);
+
 /* Bilinear (align_corners) upsample of float logits [n,h,w,c] (pixel stride
  * x_ld >= c floats) to [n,ho,wo] fused with argmax over channels (lowest index
  * wins ties); labels are uint8.  If `logits_out` is non-NULL the upsampled

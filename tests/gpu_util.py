@@ -108,6 +108,33 @@ def stem_conv(frames, w, bias, mean, scale, sub, logical_hw, stride, rate, pads,
     return out[..., :cout]
 
 
+def stem2_conv(frames, w1, b1, w2, b2, mean, scale, sub, logical_hw, pads1, hw1, act1, pads2, hw2, act2,
+               y_ld=None):
+    """Two fused 3x3 stride-2 convolutions from uint8 frames [n,hr,wr,3] (bfloat16);
+    returns the float32 host array [n,h2,w2,c2]."""
+    n, hr, wr, _ = frames.shape
+    c1, c2 = w1.shape[3], w2.shape[3]
+    xd = torch.from_numpy(frames).cuda()
+    w1d = pack_stem_weights(w1, 'bf16')
+    w2d, _, _ = pack_conv_weights(w2, 'bf16')
+    b1d = torch.from_numpy(np.asarray(b1, np.float32)).cuda()
+    b2d = torch.from_numpy(np.asarray(b2, np.float32)).cuda()
+    ld = y_ld or c2
+    y = torch.full((n, hw2[0], hw2[1], ld), -77.0, dtype=torch.bfloat16, device='cuda')
+    m3 = (ctypes.c_float * 3)(*mean)
+    s3 = (ctypes.c_float * 3)(*scale)
+    torch.cuda.synchronize()
+    _lib.call('fss_stem2_conv_u8', xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(),
+              b2d.data_ptr(), y.data_ptr(), n, hr, wr, sub, logical_hw[0], logical_hw[1], m3, s3,
+              c1, pads1[0], pads1[1], hw1[0], hw1[1], _lib.ACT_CODES[act1],
+              c2, pads2[0], pads2[1], hw2[0], hw2[1], _lib.ACT_CODES[act2], _lib.BF16, ld, None)
+    _lib.call('fss_device_sync')
+    out = to_host(y)
+    if ld != c2:
+        assert np.all(out[..., c2:] == -77.0), 'kernel wrote outside its channel slice'
+    return out[..., :c2]
+
+
 def avgpool_pyramid(x, levels, dt):
     """x: [n,h,w,c] host array; levels: list of (kh, kw); returns the list of bin maps."""
     n, h, w, c = x.shape

@@ -180,6 +180,55 @@ def test_stem_conv_u8_matches_preprocess_resize_conv(case, dt):
     _close(got, ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'stem conv %s' % dt)
 
 
+STEM2_CASES = [
+    # frame hw, padded hw, sub, c1, c2, act1, act2, y_ld
+    ((37, 70), (41, 75), 1, 64, 64, 'relu6', 'relu6', None),    # ICNet-1.0 'Conv' + 'Conv_1'
+    ((150, 300), (161, 321), 1, 64, 64, 'relu6', 'relu6', None),  # interior tiles (no masks) too
+    ((64, 128), (65, 129), 1, 32, 32, 'relu6', 'relu6', None),  # ICNet-0.5 widths, odd sizes
+    ((40, 66), (40, 66), 1, 32, 64, 'relu', None, 72),          # even sizes (asymmetric SAME pad), slice
+    ((45, 77), (47, 80), 2, 64, 32, None, 'relu', None),        # behind a half-size resize
+    ((5, 6), (5, 6), 1, 64, 64, 'relu', 'relu', None),          # smaller than one tile
+]
+
+
+@pytest.mark.parametrize('case', STEM2_CASES)
+def test_stem2_conv_u8_matches_two_layers(case):
+    """fss_stem2_conv_u8 (two 3x3 stride-2 SAME convolutions fused, the first output kept
+    in LDS) against the oracle ops chained with the intermediate rounded to bfloat16
+    (tolerance 1/128 of the output scale: one bf16 rounding), and BIT FOR BIT against
+    the unfused kernels fss_stem_conv_u8 -> fss_conv2d_nhwc."""
+    gu = _gu()
+    (hr, wr), (hp, wp), sub, c1, c2, act1, act2, y_ld = case
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    frames = rng.integers(0, 256, (2, hr, wr, 3)).astype(np.uint8)
+    mean, scale = (123.68, 116.779, 103.939), (1.0, 1.0, 1.0) if sub == 1 else (1.0, 0.5, 2.0)
+    w1 = rng.normal(0, 0.02, (3, 3, 3, c1)).astype(np.float32)
+    b1 = rng.normal(0, 1, c1).astype(np.float32)
+    w2 = rng.normal(0, 1 / np.sqrt(9 * c1), (3, 3, c1, c2)).astype(np.float32)
+    b2 = rng.normal(0, 0.5, c2).astype(np.float32)
+    img = O.pad_to_bounding_box(frames.astype(np.float32), hp, wp)
+    img = ((img - np.asarray(mean, np.float32)) * np.asarray(scale, np.float32)).astype(np.float32)
+    if sub == 2:
+        img = img[:, ::2, ::2, :]
+    hl, wl = img.shape[1:3]
+    fn = {'relu': O.relu, 'relu6': O.relu6, None: lambda v: v}
+    h1, pt1, pb1 = O.same_padding(hl, 3, 2, 1)
+    w1o, pl1, pr1 = O.same_padding(wl, 3, 2, 1)
+    h2, pt2, pb2 = O.same_padding(h1, 3, 2, 1)
+    w2o, pl2, pr2 = O.same_padding(w1o, 3, 2, 1)
+    y1 = fn[act1](O.conv2d(gu.bf16_round(img), gu.bf16_round(w1), 2, 1, (pt1, pb1, pl1, pr1), np.float64) + b1)
+    y1 = gu.bf16_round(y1.astype(np.float32))
+    ref = fn[act2](O.conv2d(y1, gu.bf16_round(w2), 2, 1, (pt2, pb2, pl2, pr2), np.float64) + b2)
+    assert ref.shape[1:3] == (h2, w2o)
+    got = gu.stem2_conv(frames, w1, b1, w2, b2, mean, scale, sub, (hl, wl), (pt1, pl1), (h1, w1o), act1,
+                        (pt2, pl2), (h2, w2o), act2, y_ld=y_ld)
+    _close(got, ref, 1.0 / 128, 'stem2 %s' % (case,))
+    # the two stand-alone kernels (16x16 MFMA shape, as the plan runs them in bfloat16)
+    mid = gu.stem_conv(frames, w1, b1, mean, scale, sub, (hl, wl), 2, 1, (pt1, pl1), (h1, w1o), act1, 'bf16')
+    two = gu.conv2d(mid, w2, b2, None, 2, 1, (pt2, pl2), (h2, w2o), act2, 'bf16', config=20)
+    assert np.array_equal(got, two), 'fused result differs from the two stand-alone kernels'
+
+
 AGREE_SHAPES = [
     # n, h, w, cin, cout, k, stride, rate, residual
     (2, 33, 65, 128, 256, 3, 1, 4, False),     # dilated, partial M tiles, taps skipped per block

@@ -11,7 +11,7 @@ for grp in \
  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
  "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_IFETCH SQ_INSTS_SMEM" ; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -o p -- python3 tools/stem_micro.py $L --iters 3 > $OUT/g$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/g$i.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -o p -- python3 tools/stem_micro.py $L --iters 3 --batch ${BATCH:-16} > $OUT/g$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/g$i.log; exit 1; }
 done
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
@@ -21,7 +21,7 @@ for path in sorted(glob.glob(out + '/g*/**/*counter_collection.csv', recursive=T
     per = collections.defaultdict(list)
     with open(path) as f:
         for r in csv.DictReader(f):
-            if 'stem_conv_kernel' in r['Kernel_Name']:
+            if 'stem_conv_kernel' in r['Kernel_Name'] or 'stem2_conv_kernel' in r['Kernel_Name']:
                 per[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in per.items():
         acc[k] = sum(v[-3:]) / len(v[-3:])
