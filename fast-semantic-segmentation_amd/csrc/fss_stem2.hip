@@ -16,14 +16,21 @@
 // ends up with consecutive output channels of one pixel.  The second filter never
 // touches LDS: wave (ch, pp) owns 32 output channels and a share of the tile's rows, and
 // keeps its 9 * C1/32 * 2 weight fragments in registers for the whole (persistent) block.
-// The k order of both convolutions is the one the stand-alone kernels use (tap-major,
-// channels inside a tap), and y1 is rounded to bf16 exactly where the unfused path
-// stores it, so the result equals running the two layers one after the other.
+// y1 is rounded to bf16 exactly where the unfused path stores it, so the result equals
+// running the two layers one after the other up to the order of the float additions.
+//
+// conv1's K axis is 64 slots of 4 channels: step 0 holds taps 0-7 (lane group g: taps g and
+// g + 4, so that the two lane groups served together by a ds_read_b64 read pixels of
+// opposite column parity and never share a bank), step 1 holds tap 8 and, against a
+// constant 1.0 in the B operand, the bias as a bf16 pair (high part + remainder), which
+// makes the bias part of the MFMA sum.  Index arithmetic per pixel group (patch address of
+// the lane's pixel, y1 address, position for the border mask) comes from a table built
+// once per block.
 //
 // y1 tile layout: pixel (i, j) lives at pixel slot i*33 + (j&1)*17 + (j>>1) (columns
 // split by parity: a stride-2 tap reads 16 consecutive slots) and its 16-byte chunk c
-// is stored at chunk c ^ f(j>>1), which spreads the 16 lanes of every ds_read_b128
-// service group over all banks.
+// is stored at chunk c ^ f(j>>1, j&1); f spreads the 16 lanes of every ds_read_b128
+// service group, and the 8 lanes of every ds_write_b128 group, over all banks.
 #include <algorithm>
 
 #include "fss_common.h"
@@ -55,6 +62,18 @@ constexpr int kS2PW = 2 * kS2Y1W + 1;      // patch columns
 constexpr int kS2K4 = 64;                  // conv1 K: 9 taps x 4 channels, padded to two MFMA steps
 constexpr int kS2WRow = kS2K4 * 2 + 16;    // LDS bytes per conv1 weight row (+16: distinct banks)
 
+// LDS map of a block
+template <int KS1, int TH2> struct Stem2Lds {
+  static constexpr int R1 = 2 * TH2 + 1;                       // y1 rows of a tile
+  static constexpr int PP = (2 * R1 + 1) * kS2PW;              // patch pixels
+  static constexpr int G1 = (R1 * kS2Y1W + 15) / 16;           // conv1 pixel groups of a tile
+  static constexpr int OFF_B2 = 0, OFF_W1 = 256;
+  static constexpr int OFF_TAB = OFF_W1 + 32 * KS1 * kS2WRow;
+  static constexpr int OFF_PATCH = OFF_TAB + G1 * 64 * 8;
+  static constexpr int OFF_Y1 = (OFF_PATCH + PP * 8 + 255) / 256 * 256;
+  static constexpr int BYTES = OFF_Y1 + R1 * kS2Y1W * 64 * KS1;
+};
+
 // KS1 = C1 / 32, CW = C2 / 32, TH2 = output rows per tile, NW = waves per block
 template <int KS1, int CW, int TH2, int NW>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
@@ -64,7 +83,6 @@ stem2_conv_kernel(const Stem2Args a) {
   constexpr int PH = 2 * R1 + 1;             // patch rows
   constexpr int PP = PH * kS2PW;             // patch pixels
   constexpr int FS = (PP + NT - 1) / NT;     // patch pixels per thread
-  constexpr int NJ1 = 2 * KS1;               // 16-channel groups of conv1
   constexpr int PXB = 64 * KS1;              // bytes of one y1 pixel
   constexpr int CPP = PXB / 16;              // chunks per y1 pixel (4 or 8)
   constexpr int Y1PIX = R1 * kS2Y1W;
@@ -75,34 +93,61 @@ stem2_conv_kernel(const Stem2Args a) {
   static_assert(TH2 * CW % NW == 0 && PGW >= 1, "rows must split evenly over the waves");
   static_assert(KS1 == 1 || KS1 == 2, "C1 must be 32 or 64");
 
-  constexpr int OFF_B1 = 0, OFF_B2 = 256, OFF_W1 = 512;
-  constexpr int OFF_PATCH = OFF_W1 + NJ1 * 16 * kS2WRow;
-  constexpr int OFF_Y1 = (OFF_PATCH + PP * 8 + 255) / 256 * 256;
+  typedef Stem2Lds<KS1, TH2> L;
+  static_assert(L::PP == PP && L::G1 == G1, "LDS map out of step with the kernel");
+  constexpr int OFF_B2 = L::OFF_B2, OFF_W1 = L::OFF_W1, OFF_TAB = L::OFF_TAB, OFF_PATCH = L::OFF_PATCH,
+                OFF_Y1 = L::OFF_Y1;
 
   extern __shared__ __attribute__((aligned(256))) char smem[];
-  float* lb1 = reinterpret_cast<float*>(smem + OFF_B1);
   float* lb2 = reinterpret_cast<float*>(smem + OFF_B2);
   char* wl = smem + OFF_W1;
+  uint2* tab = reinterpret_cast<uint2*>(smem + OFF_TAB);
   char* patch = smem + OFF_PATCH;
   char* y1 = smem + OFF_Y1;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int p = lane & 15, g = lane >> 4;
-  auto swz = [](int hc) { return CPP == 8 ? ((hc >> 1) & 7) : ((hc >> 2) & 3); };
+  // XOR term of the chunk index of y1 pixel slot hc in the plane of column parity par
+  auto swz = [](int hc, int par) {
+    return CPP == 8 ? (((hc >> 1) ^ ((hc & 1) << 1) ^ (par << 2)) & 7)
+                    : (((hc >> 2) ^ ((hc >> 1) & 1) ^ (par << 1)) & 3);
+  };
 
   // ---- per-block tables
-  if (tid < 64) {
-    lb1[tid] = tid < 32 * KS1 ? a.b1[tid] : 0.f;
-    lb2[tid] = tid < 32 * CW ? a.b2[tid] : 0.f;
-  }
-  {  // conv1 weights, one padded row per output channel
-    constexpr int cpr = kS2K4 * 2 / 16;
-    for (int idx = tid; idx < 32 * KS1 * cpr; idx += NT) {
-      const int co = idx / cpr, c = idx - co * cpr;
-      *reinterpret_cast<uint4*>(wl + co * kS2WRow + c * 16) = *reinterpret_cast<const uint4*>(
-          reinterpret_cast<const char*>(a.w1) + ((size_t)co * kS2K4 * 2 + c * 16));
+  if (tid < 64) lb2[tid] = tid < 32 * CW ? a.b2[tid] : 0.f;
+  {  // conv1 weights, one padded row per output channel, 16 slots of 4 k values:
+     // slot (st, g, half) = tap g + 4*half for st = 0; tap 8 for (1, 0, 0); the bias as
+     // bf16 high part + remainder for (1, 0, 1); zero otherwise
+    for (int idx = tid; idx < 32 * KS1 * 16; idx += NT) {
+      const int co = idx >> 4, slot = idx & 15;
+      const int st = slot >> 3, sg = (slot >> 1) & 3, half = slot & 1;
+      const int tap = st == 0 ? sg + 4 * half : (sg == 0 && half == 0 ? 8 : -1);
+      uint2 v = make_uint2(0u, 0u);
+      if (tap >= 0) {
+        v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.w1) + ((size_t)co * kS2K4 * 2 + tap * 8));
+      } else if (st == 1 && sg == 0) {
+        const float b = a.b1[co];
+        const unsigned hi = f32_to_bf16(b);
+        const unsigned lo = f32_to_bf16(b - bf16_to_f32((bf16_t)hi));
+        v.x = hi | (lo << 16);
+      }
+      *reinterpret_cast<uint2*>(wl + co * kS2WRow + (32 * st + 8 * sg + 4 * half) * 2) = v;
     }
+  }
+  // pixel group table: lane l of group grp is pixel 16*grp + (l & 15) = (i, j) of the y1 tile.
+  //   .x = i << 20 | j << 14 | byte offset of patch pixel (2i, 2j)
+  //   .y = byte offset of the lane's chunk (l >> 4) in the y1 tile (channel half 0), -1 past the tile
+  for (int idx = tid; idx < G1 * 64; idx += NT) {
+    const int l = idx & 63, pix = 16 * (idx >> 6) + (l & 15);
+    const int pc = min(pix, Y1PIX - 1);
+    const int i = pc / kS2Y1W, j = pc - i * kS2Y1W;
+    const int hc = j >> 1, par = j & 1;
+    uint2 e;
+    e.x = ((unsigned)i << 20) | ((unsigned)j << 14) | (unsigned)(((2 * i) * kS2PW + 2 * j) * 8);
+    e.y = pix < Y1PIX ? (unsigned)((i * kS2Y1W + par * kS2Even + hc) * PXB + (((l >> 4) ^ swz(hc, par)) & (CPP - 1)) * 16)
+                      : 0xffffffffu;
+    tab[idx] = e;
   }
 
   // ---- conv2 weights: this wave's 32 output channels, in registers for good.
@@ -124,18 +169,22 @@ stem2_conv_kernel(const Stem2Args a) {
   // ---- conv1: wave (c1h, gs) makes 32 channels (c1h) of the pixel groups gs, gs + GS, ...;
   // lane (p, g) of group grp is pixel 16*grp + p of the y1 tile, channels 32*c1h + 8*g .. +7
   const int c1h = wave % KS1, gs = wave / KS1;
-  // patch offsets of this lane group's conv1 taps: k step 0 holds taps 2g, 2g+1; step 1 tap 8
-  // (lane group 0) and zero weights (they read pixel 0 of the group: any finite value)
-  const int t0 = 2 * g, t1 = 2 * g + 1;
-  const int to00 = (t0 / 3) * kS2PW + t0 % 3, to01 = (t1 / 3) * kS2PW + t1 % 3;
-  const int to10 = g == 0 ? 2 * kS2PW + 2 : 0;
+  // byte offsets, from the lane's patch pixel, of this lane group's conv1 taps: taps g and
+  // g + 4 in k step 0; in step 1 tap 8 for lane group 0, else a pixel of the group's own
+  // column parity (its weights are zero: any finite value will do)
+  auto tap_off = [](int t) { return ((t / 3) * kS2PW + t % 3) * 8; };
+  const int toA = tap_off(g), toB = tap_off(g + 4), toC = g == 0 ? tap_off(8) : (g & 1) * 8;
+  const unsigned one_pair = g == 0 ? 0x3f803f80u : 0u;   // B operand of the bias slots: 1.0, 1.0
 
   // ---- conv2 read offsets of this lane: pixel slot p + e (e = tap column >> 1), chunk 4*kh + g
-  int roff[2][KS1];
+  // (one per tap column s: plane s & 1, slot p + (s >> 1))
+  int roff[3][KS1];
 #pragma unroll
-  for (int e = 0; e < 2; ++e)
+  for (int sc = 0; sc < 3; ++sc)
 #pragma unroll
-    for (int kh = 0; kh < KS1; ++kh) roff[e][kh] = (p + e) * PXB + (((4 * kh + g) ^ swz(p + e)) & (CPP - 1)) * 16;
+    for (int kh = 0; kh < KS1; ++kh)
+      roff[sc][kh] = ((sc & 1) * kS2Even + p + (sc >> 1)) * PXB +
+                     (((4 * kh + g) ^ swz(p + (sc >> 1), sc & 1)) & (CPP - 1)) * 16;
 
   const float lo1 = a.act1 == FSS_ACT_NONE ? -INFINITY : 0.f, hi1 = a.act1 == FSS_ACT_RELU6 ? 6.f : INFINITY;
   const float lo2 = a.act2 == FSS_ACT_NONE ? -INFINITY : 0.f, hi2 = a.act2 == FSS_ACT_RELU6 ? 6.f : INFINITY;
@@ -213,36 +262,43 @@ stem2_conv_kernel(const Stem2Args a) {
   // zero fill of the bounding box, mean / scale, zero padding of conv1, rounding
   auto commit = [&](const Tile& t, const unsigned (&u)[FS]) {
     const int i0 = y1_i0(t) * 2 - a.pad_t1, j0 = y1_j0(t) * 2 - a.pad_l1;
-    const bool interior = patch_interior(t);
-#pragma unroll
-    for (int k = 0; k < FS; ++k) {
-      int pi, pj;
-      const bool slot = patch_rc(k, pi, pj);
-      float v[3];
-      if (interior) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          v[c] = (float)((u[k] >> (8 * c)) & 255u) - a.mean[c];
-          if (!a.unit_scale) v[c] *= a.scale[c];
-        }
-      } else {
-        const int i = i0 + pi, j = j0 + pj;
-        const bool real = (unsigned)i < (unsigned)hreal && (unsigned)j < (unsigned)wreal;
-        const bool inside = (unsigned)i < (unsigned)a.H && (unsigned)j < (unsigned)a.W;
-        const float m_real = real ? 1.f : 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          v[c] = fmaf((float)((u[k] >> (8 * c)) & 255u), m_real, -a.mean[c]);    // exact: (u or 0) - mean
-          if (!a.unit_scale) v[c] *= a.scale[c];
-          v[c] = inside ? v[c] : 0.f;
-        }
-      }
+    auto store = [&](int k, bool slot, const float (&v)[3]) {
       if (slot) {
         uint2 o;
         o.x = pack_bf16x2(v[0], v[1]);
         o.y = pack_bf16x2(v[2], 0.f);
         *reinterpret_cast<uint2*>(patch + (size_t)(tid + NT * k) * 8) = o;
       }
+    };
+    if (patch_interior(t)) {
+#pragma unroll
+      for (int k = 0; k < FS; ++k) {
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          v[c] = (float)((u[k] >> (8 * c)) & 255u) - a.mean[c];
+          if (!a.unit_scale) v[c] *= a.scale[c];
+        }
+        store(k, tid + NT * k < PP, v);
+      }
+      return;
+    }
+#pragma unroll
+    for (int k = 0; k < FS; ++k) {
+      int pi, pj;
+      const bool slot = patch_rc(k, pi, pj);
+      const int i = i0 + pi, j = j0 + pj;
+      const bool real = (unsigned)i < (unsigned)hreal && (unsigned)j < (unsigned)wreal;
+      const bool inside = (unsigned)i < (unsigned)a.H && (unsigned)j < (unsigned)a.W;
+      const float m_real = real ? 1.f : 0.f;
+      float v[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v[c] = fmaf((float)((u[k] >> (8 * c)) & 255u), m_real, -a.mean[c]);    // exact: (u or 0) - mean
+        if (!a.unit_scale) v[c] *= a.scale[c];
+        v[c] = inside ? v[c] : 0.f;
+      }
+      store(k, slot, v);
     }
   };
 
@@ -266,60 +322,51 @@ stem2_conv_kernel(const Stem2Args a) {
         for (int nj = 0; nj < 2; ++nj)
           w1f[st][nj] = *reinterpret_cast<const uint4*>(
               wl + (32 * c1h + 8 * (p >> 2) + 4 * nj + (p & 3)) * kS2WRow + (32 * st + 8 * g) * 2);
-      const float4 bb0 = *reinterpret_cast<const float4*>(lb1 + 32 * c1h + 8 * g);
-      const float4 bb1 = *reinterpret_cast<const float4*>(lb1 + 32 * c1h + 8 * g + 4);
       const int i1_0 = y1_i0(now), j1_0 = y1_j0(now);
       // pixels of the tile that lie outside conv1's output are conv2's zero padding
       const bool y1_interior = i1_0 >= 0 && j1_0 >= 0 && i1_0 + R1 <= a.H1 && j1_0 + kS2Y1W <= a.W1;
-      // pixel (i, j) of this lane in group gs + GS*t, advanced by 16*GS pixels per step
-      constexpr int STEP_I = 16 * GS / kS2Y1W, STEP_J = 16 * GS % kS2Y1W;
-      int i = (16 * gs + p) / kS2Y1W, j = (16 * gs + p) % kS2Y1W;
-      // the B operands (patch pixels of this lane's taps) of a group: k step 0 = b[0], b[1],
-      // k step 1 = b[2], b[3]
-      auto load_b = [&](int ii, int jj, uint2 (&b)[4]) {
-        const char* src = patch + (size_t)((2 * ii) * kS2PW + 2 * jj) * 8;
-        b[0] = *reinterpret_cast<const uint2*>(src + to00 * 8);
-        b[1] = *reinterpret_cast<const uint2*>(src + to01 * 8);
-        b[2] = *reinterpret_cast<const uint2*>(src + to10 * 8);
-        b[3] = *reinterpret_cast<const uint2*>(src);
+      // table entry and B operands (patch pixels of this lane's taps) of a group, fetched one
+      // group ahead
+      auto load_b = [&](const uint2& e, uint2 (&b)[3]) {
+        const char* src = patch + (e.x & 0x3fffu);
+        b[0] = *reinterpret_cast<const uint2*>(src + toA);
+        b[1] = *reinterpret_cast<const uint2*>(src + toB);
+        b[2] = *reinterpret_cast<const uint2*>(src + toC);
       };
-      uint2 bq[4];
-      load_b(min(i, R1 - 1), j, bq);
+      uint2 en = tab[gs * 64 + lane];
+      uint2 bq[3];
+      load_b(en, bq);
 #pragma unroll 2
       for (int t = 0; t < G1W; ++t) {
-        if (16 * (gs + GS * t) >= Y1PIX) break;                    // wave-uniform
-        const int ci = i, cj = j;
-        uint2 bc[4] = {bq[0], bq[1], bq[2], bq[3]};
-        j += STEP_J;
-        i += STEP_I;
-        if (j >= kS2Y1W) { j -= kS2Y1W; ++i; }
-        load_b(min(i, R1 - 1), j, bq);      // next group's operands (clamped past the tile: unused)
+        const int grp = gs + GS * t;
+        if (grp >= G1) break;                                      // wave-uniform
+        const uint2 ec = en;
+        const uint2 bc[3] = {bq[0], bq[1], bq[2]};
+        en = tab[min(grp + GS, G1 - 1) * 64 + lane];               // past the last group: unused
+        load_b(en, bq);
         f32x4 acc[2];
         acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint4 b0 = make_uint4(bc[0].x, bc[0].y, bc[1].x, bc[1].y);
+        const uint4 b1 = make_uint4(bc[2].x, bc[2].y, one_pair, 0u);
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-          const uint4 b = make_uint4(bc[2 * st].x, bc[2 * st].y, bc[2 * st + 1].x, bc[2 * st + 1].y);
-#pragma unroll
-          for (int nj = 0; nj < 2; ++nj)
-            acc[nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1f[st][nj]),
-                                                              __builtin_bit_cast(bf16x8_t, b), acc[nj], 0, 0, 0);
+        for (int nj = 0; nj < 2; ++nj) {
+          acc[nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1f[0][nj]),
+                                                            __builtin_bit_cast(bf16x8_t, b0), acc[nj], 0, 0, 0);
+          acc[nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1f[1][nj]),
+                                                            __builtin_bit_cast(bf16x8_t, b1), acc[nj], 0, 0, 0);
         }
-        float v[8] = {acc[0][0] + bb0.x, acc[0][1] + bb0.y, acc[0][2] + bb0.z, acc[0][3] + bb0.w,
-                      acc[1][0] + bb1.x, acc[1][1] + bb1.y, acc[1][2] + bb1.z, acc[1][3] + bb1.w};
+        float v[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = __builtin_amdgcn_fmed3f(v[q], lo1, hi1);
         uint4 o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
                              pack_bf16x2(v[6], v[7]));
         if (!y1_interior) {
+          const int ci = (int)(ec.x >> 20), cj = (int)((ec.x >> 14) & 63u);
           const bool inside = (unsigned)(i1_0 + ci) < (unsigned)a.H1 && (unsigned)(j1_0 + cj) < (unsigned)a.W1;
           const unsigned m = inside ? 0xffffffffu : 0u;
           o.x &= m; o.y &= m; o.z &= m; o.w &= m;
         }
-        if (ci < R1) {
-          const int hc = cj >> 1;
-          char* dst = y1 + (ci * kS2Y1W + (cj & 1) * kS2Even + hc) * PXB + ((4 * c1h + g) ^ swz(hc)) * 16;
-          *reinterpret_cast<uint4*>(dst) = o;
-        }
+        if (ec.y != 0xffffffffu) *reinterpret_cast<uint4*>(y1 + (ec.y ^ (unsigned)(c1h << 6))) = o;
       }
     }
     __syncthreads();   // y1 tile complete; every wave is done with the patch
@@ -341,8 +388,7 @@ stem2_conv_kernel(const Stem2Args a) {
         for (int kh = 0; kh < KS1; ++kh)
 #pragma unroll
           for (int t = 0; t < PGW; ++t) {
-            const uint4 b = *reinterpret_cast<const uint4*>(
-                rowp + ((2 * t + r) * kS2Y1W + (s & 1) * kS2Even) * PXB + roff[s >> 1][kh]);
+            const uint4 b = *reinterpret_cast<const uint4*>(rowp + ((2 * t + r) * kS2Y1W) * PXB + roff[s][kh]);
 #pragma unroll
             for (int nj = 0; nj < 2; ++nj)
               acc2[t][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -375,10 +421,7 @@ stem2_conv_kernel(const Stem2Args a) {
 template <int KS1, int CW, int TH2, int NW>
 static int launch_stem2(const Stem2Args& a0, hipStream_t stream) {
   Stem2Args a = a0;
-  constexpr int R1 = 2 * TH2 + 1, PH = 2 * R1 + 1, PP = PH * kS2PW;
-  constexpr size_t off_patch = 512 + (size_t)(2 * KS1) * 16 * kS2WRow;
-  constexpr size_t off_y1 = (off_patch + (size_t)PP * 8 + 255) / 256 * 256;
-  constexpr size_t smem = off_y1 + (size_t)R1 * kS2Y1W * 64 * KS1;
+  constexpr size_t smem = Stem2Lds<KS1, TH2>::BYTES;
   static_assert(smem <= 160 * 1024, "tile too large for LDS");
   a.tiles_x = ceil_div(a.W2, kS2TW);
   a.tiles_y = ceil_div(a.H2, TH2);
