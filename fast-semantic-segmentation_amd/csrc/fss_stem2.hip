@@ -16,6 +16,13 @@
 // ends up with consecutive output channels of one pixel.  The second filter never
 // touches LDS: wave (ch, pp) owns 32 output channels and a share of the tile's rows, and
 // keeps its 9 * C1/32 * 2 weight fragments in registers for the whole (persistent) block.
+//
+// A block is a two-stage pipeline over its tiles with double-buffered patch and y1 tile:
+// waves 0..NW-1 ("producers") run conv1 of tile k-1 while waves NW..2NW-1 ("consumers")
+// run conv2 of tile k-2, stage the patch of tile k and request the bytes of tile k+1; one
+// barrier per step separates the steps.  Every SIMD hosts one wave of each kind, so the
+// first layer's index and conversion work overlaps the second layer's MFMAs.
+//
 // y1 is rounded to bf16 exactly where the unfused path stores it, so the result equals
 // running the two layers one after the other up to the order of the float additions.
 //
@@ -32,6 +39,8 @@
 // is stored at chunk c ^ f(j>>1, j&1); f spreads the 16 lanes of every ds_read_b128
 // service group, and the 8 lanes of every ds_write_b128 group, over all banks.
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 
 #include "fss_common.h"
 
@@ -39,6 +48,26 @@ namespace fss {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// f(integral_constant<B>), ..., f(integral_constant<E-1>)
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+
+// 16-byte LDS read whose latency the compiler does not wait for: the consumer calls
+// lds_wait<N>(dst) before the first use, N = reads issued after this one (LDS returns in
+// order).  The compiler's own lgkmcnt waits stay correct: they can only wait longer.
+template <int OFFSET> __device__ __forceinline__ void lds_read16_async(u32x4_t& dst, unsigned lds_addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_addr), "n"(OFFSET) : "memory");
+}
+template <int N> __device__ __forceinline__ void lds_wait(u32x4_t& r) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(r) : "n"(N) : "memory");
+}
 
 struct Stem2Args {
   const uint8_t* x;
@@ -70,15 +99,17 @@ template <int KS1, int TH2> struct Stem2Lds {
   static constexpr int OFF_B2 = 0, OFF_W1 = 256;
   static constexpr int OFF_TAB = OFF_W1 + 32 * KS1 * kS2WRow;
   static constexpr int OFF_PATCH = OFF_TAB + G1 * 64 * 8;
-  static constexpr int OFF_Y1 = (OFF_PATCH + PP * 8 + 255) / 256 * 256;
-  static constexpr int BYTES = OFF_Y1 + R1 * kS2Y1W * 64 * KS1;
+  static constexpr int PATCH_BYTES = (PP * 8 + 15) / 16 * 16;               // two of them
+  static constexpr int OFF_Y1 = (OFF_PATCH + 2 * PATCH_BYTES + 255) / 256 * 256;
+  static constexpr int Y1_BYTES = (R1 * kS2Y1W * 64 * KS1 + 255) / 256 * 256;   // two of them
+  static constexpr int BYTES = OFF_Y1 + 2 * Y1_BYTES;
 };
 
-// KS1 = C1 / 32, CW = C2 / 32, TH2 = output rows per tile, NW = waves per block
+// KS1 = C1 / 32, CW = C2 / 32, TH2 = output rows per tile, NW = waves of each kind per block
 template <int KS1, int CW, int TH2, int NW>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(2 * NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
 stem2_conv_kernel(const Stem2Args a) {
-  constexpr int NT = NW * 64;
+  constexpr int NT = NW * 64;                // threads of each kind
   constexpr int R1 = 2 * TH2 + 1;            // y1 rows of a tile
   constexpr int PH = 2 * R1 + 1;             // patch rows
   constexpr int PP = PH * kS2PW;             // patch pixels
@@ -102,11 +133,14 @@ stem2_conv_kernel(const Stem2Args a) {
   float* lb2 = reinterpret_cast<float*>(smem + OFF_B2);
   char* wl = smem + OFF_W1;
   uint2* tab = reinterpret_cast<uint2*>(smem + OFF_TAB);
-  char* patch = smem + OFF_PATCH;
-  char* y1 = smem + OFF_Y1;
+  char* const patch0 = smem + OFF_PATCH;
+  char* const y10 = smem + OFF_Y1;
 
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int btid = threadIdx.x;              // thread of the block: only for the shared tables
+  const int bwave = __builtin_amdgcn_readfirstlane(btid >> 6), lane = btid & 63;
+  const bool consumer = bwave >= NW;
+  const int wave = consumer ? bwave - NW : bwave;      // wave and thread inside its kind
+  const int tid = wave * 64 + lane;
   const int p = lane & 15, g = lane >> 4;
   // XOR term of the chunk index of y1 pixel slot hc in the plane of column parity par
   auto swz = [](int hc, int par) {
@@ -115,11 +149,11 @@ stem2_conv_kernel(const Stem2Args a) {
   };
 
   // ---- per-block tables
-  if (tid < 64) lb2[tid] = tid < 32 * CW ? a.b2[tid] : 0.f;
+  if (btid < 64) lb2[btid] = btid < 32 * CW ? a.b2[btid] : 0.f;
   {  // conv1 weights, one padded row per output channel, 16 slots of 4 k values:
      // slot (st, g, half) = tap g + 4*half for st = 0; tap 8 for (1, 0, 0); the bias as
      // bf16 high part + remainder for (1, 0, 1); zero otherwise
-    for (int idx = tid; idx < 32 * KS1 * 16; idx += NT) {
+    for (int idx = btid; idx < 32 * KS1 * 16; idx += 2 * NT) {
       const int co = idx >> 4, slot = idx & 15;
       const int st = slot >> 3, sg = (slot >> 1) & 3, half = slot & 1;
       const int tap = st == 0 ? sg + 4 * half : (sg == 0 && half == 0 ? 8 : -1);
@@ -138,7 +172,7 @@ stem2_conv_kernel(const Stem2Args a) {
   // pixel group table: lane l of group grp is pixel 16*grp + (l & 15) = (i, j) of the y1 tile.
   //   .x = i << 20 | j << 14 | byte offset of patch pixel (2i, 2j)
   //   .y = byte offset of the lane's chunk (l >> 4) in the y1 tile (channel half 0), -1 past the tile
-  for (int idx = tid; idx < G1 * 64; idx += NT) {
+  for (int idx = btid; idx < G1 * 64; idx += 2 * NT) {
     const int l = idx & 63, pix = 16 * (idx >> 6) + (l & 15);
     const int pc = min(pix, Y1PIX - 1);
     const int i = pc / kS2Y1W, j = pc - i * kS2Y1W;
@@ -150,21 +184,7 @@ stem2_conv_kernel(const Stem2Args a) {
     tab[idx] = e;
   }
 
-  // ---- conv2 weights: this wave's 32 output channels, in registers for good.
-  // A-row r of tile nj is channel 32*ch + 8*(r>>2) + 4*nj + (r&3): lane group g then holds
-  // the 8 consecutive channels 32*ch + 8*g .. +7 of its pixel.
-  const int ch = wave % CW, pp = wave / CW;
-  uint4 w2f[9][KS1][2];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int kh = 0; kh < KS1; ++kh)
-#pragma unroll
-      for (int nj = 0; nj < 2; ++nj) {
-        const int co = 32 * ch + 8 * (p >> 2) + 4 * nj + (p & 3);
-        w2f[t][kh][nj] = *reinterpret_cast<const uint4*>(
-            reinterpret_cast<const bf16_t*>(a.w2) + (size_t)co * a.w2_kpad + t * (32 * KS1) + kh * 32 + 8 * g);
-      }
+  const int ch = wave % CW, pp = wave / CW;      // consumer: channel half, share of the rows
 
   // ---- conv1: wave (c1h, gs) makes 32 channels (c1h) of the pixel groups gs, gs + GS, ...;
   // lane (p, g) of group grp is pixel 16*grp + p of the y1 tile, channels 32*c1h + 8*g .. +7
@@ -260,7 +280,7 @@ stem2_conv_kernel(const Stem2Args a) {
     }
   };
   // zero fill of the bounding box, mean / scale, zero padding of conv1, rounding
-  auto commit = [&](const Tile& t, const unsigned (&u)[FS]) {
+  auto commit = [&](const Tile& t, const unsigned (&u)[FS], char* patch) {
     const int i0 = y1_i0(t) * 2 - a.pad_t1, j0 = y1_j0(t) * 2 - a.pad_l1;
     auto store = [&](int k, bool slot, const float (&v)[3]) {
       if (slot) {
@@ -302,118 +322,182 @@ stem2_conv_kernel(const Stem2Args a) {
     }
   };
 
-  unsigned ureg[FS];
-  Tile cur = decode(blockIdx.x);
-  fetch(cur, ureg);
-  for (int tile = blockIdx.x; tile < a.total_tiles; tile += gridDim.x) {
-    // every wave is past the previous tile's conv1 (barrier below), so the patch is free
-    commit(cur, ureg);
-    __syncthreads();   // patch complete (first pass: LDS tables too); previous conv2 reads of y1 done
-    const Tile now = cur;
-    // past the last tile this re-reads the current one: harmless, and keeps the loop branch-free
-    if (tile + (int)gridDim.x < a.total_tiles) cur = advance(cur);
-
-    // ---------------- conv1: patch -> y1 tile
-    {
-      uint4 w1f[2][2];
+  // ---- the two stages
+  auto conv1 = [&](const Tile& now, const char* patch, char* y1) {
+    uint4 w1f[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+        w1f[st][nj] = *reinterpret_cast<const uint4*>(
+            wl + (32 * c1h + 8 * (p >> 2) + 4 * nj + (p & 3)) * kS2WRow + (32 * st + 8 * g) * 2);
+    const int i1_0 = y1_i0(now), j1_0 = y1_j0(now);
+    // pixels of the tile that lie outside conv1's output are conv2's zero padding
+    const bool y1_interior = i1_0 >= 0 && j1_0 >= 0 && i1_0 + R1 <= a.H1 && j1_0 + kS2Y1W <= a.W1;
+    // Two pixel groups per iteration (four independent MFMA chains, the epilogue of one
+    // group under the MFMAs of the other); table entries are read two iterations ahead and
+    // the B operands (patch pixels of this lane's taps) one iteration ahead, so that no LDS
+    // latency sits in front of the MFMAs.  Groups past the tile are computed on clamped
+    // indices and not stored.
+    auto load_b = [&](const uint2& e, uint2 (&b)[3]) {
+      const char* src = patch + (e.x & 0x3fffu);
+      b[0] = *reinterpret_cast<const uint2*>(src + toA);
+      b[1] = *reinterpret_cast<const uint2*>(src + toB);
+      b[2] = *reinterpret_cast<const uint2*>(src + toC);
+    };
+    auto entry = [&](int grp) { return tab[min(grp, G1 - 1) * 64 + lane]; };
+    constexpr int NPAIR = (G1W + 1) / 2;
+    uint2 en[2] = {entry(gs), entry(gs + GS)};
+    uint2 en2[2] = {entry(gs + 2 * GS), entry(gs + 3 * GS)};
+    uint2 bq[2][3];
+    load_b(en[0], bq[0]);
+    load_b(en[1], bq[1]);
+#pragma unroll 1
+    for (int t = 0; t < NPAIR; ++t) {
+      const int grp0 = gs + GS * (2 * t);
+      const uint2 ec[2] = {en[0], en[1]};
+      uint2 bc[2][3];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) bc[u][q] = bq[u][q];
+      en[0] = en2[0];
+      en[1] = en2[1];
+      en2[0] = entry(grp0 + 4 * GS);
+      en2[1] = entry(grp0 + 5 * GS);
+      load_b(en[0], bq[0]);
+      load_b(en[1], bq[1]);
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[u][0] = acc[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-          w1f[st][nj] = *reinterpret_cast<const uint4*>(
-              wl + (32 * c1h + 8 * (p >> 2) + 4 * nj + (p & 3)) * kS2WRow + (32 * st + 8 * g) * 2);
-      const int i1_0 = y1_i0(now), j1_0 = y1_j0(now);
-      // pixels of the tile that lie outside conv1's output are conv2's zero padding
-      const bool y1_interior = i1_0 >= 0 && j1_0 >= 0 && i1_0 + R1 <= a.H1 && j1_0 + kS2Y1W <= a.W1;
-      // table entry and B operands (patch pixels of this lane's taps) of a group, fetched one
-      // group ahead
-      auto load_b = [&](const uint2& e, uint2 (&b)[3]) {
-        const char* src = patch + (e.x & 0x3fffu);
-        b[0] = *reinterpret_cast<const uint2*>(src + toA);
-        b[1] = *reinterpret_cast<const uint2*>(src + toB);
-        b[2] = *reinterpret_cast<const uint2*>(src + toC);
-      };
-      uint2 en = tab[gs * 64 + lane];
-      uint2 bq[3];
-      load_b(en, bq);
-#pragma unroll 2
-      for (int t = 0; t < G1W; ++t) {
-        const int grp = gs + GS * t;
-        if (grp >= G1) break;                                      // wave-uniform
-        const uint2 ec = en;
-        const uint2 bc[3] = {bq[0], bq[1], bq[2]};
-        en = tab[min(grp + GS, G1 - 1) * 64 + lane];               // past the last group: unused
-        load_b(en, bq);
-        f32x4 acc[2];
-        acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const uint4 b0 = make_uint4(bc[0].x, bc[0].y, bc[1].x, bc[1].y);
-        const uint4 b1 = make_uint4(bc[2].x, bc[2].y, one_pair, 0u);
+        for (int u = 0; u < 2; ++u) {
+          const uint4 b = st == 0 ? make_uint4(bc[u][0].x, bc[u][0].y, bc[u][1].x, bc[u][1].y)
+                                  : make_uint4(bc[u][2].x, bc[u][2].y, one_pair, 0u);
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj) {
-          acc[nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1f[0][nj]),
-                                                            __builtin_bit_cast(bf16x8_t, b0), acc[nj], 0, 0, 0);
-          acc[nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1f[1][nj]),
-                                                            __builtin_bit_cast(bf16x8_t, b1), acc[nj], 0, 0, 0);
+          for (int nj = 0; nj < 2; ++nj)
+            acc[u][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1f[st][nj]),
+                                                                 __builtin_bit_cast(bf16x8_t, b), acc[u][nj], 0, 0, 0);
         }
-        float v[8] = {acc[0][0], acc[0][1], acc[0][2], acc[0][3], acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float v[8] = {acc[u][0][0], acc[u][0][1], acc[u][0][2], acc[u][0][3],
+                      acc[u][1][0], acc[u][1][1], acc[u][1][2], acc[u][1][3]};
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = __builtin_amdgcn_fmed3f(v[q], lo1, hi1);
         uint4 o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
                              pack_bf16x2(v[6], v[7]));
         if (!y1_interior) {
-          const int ci = (int)(ec.x >> 20), cj = (int)((ec.x >> 14) & 63u);
+          const int ci = (int)(ec[u].x >> 20), cj = (int)((ec[u].x >> 14) & 63u);
           const bool inside = (unsigned)(i1_0 + ci) < (unsigned)a.H1 && (unsigned)(j1_0 + cj) < (unsigned)a.W1;
           const unsigned m = inside ? 0xffffffffu : 0u;
           o.x &= m; o.y &= m; o.z &= m; o.w &= m;
         }
-        if (ec.y != 0xffffffffu) *reinterpret_cast<uint4*>(y1 + (ec.y ^ (unsigned)(c1h << 6))) = o;
+        if (grp0 + GS * u < G1 && ec[u].y != 0xffffffffu)
+          *reinterpret_cast<uint4*>(y1 + (ec[u].y ^ (unsigned)(c1h << 6))) = o;
       }
     }
-    __syncthreads();   // y1 tile complete; every wave is done with the patch
-    // the next tile's bytes are in flight during conv2 and the stores
-    fetch(cur, ureg);
-
-    // ---------------- conv2: y1 tile -> output
-    f32x4 acc2[PGW][2];
+  };
+  // ---- pipeline over this block's tiles blockIdx.x + k*gridDim.x, k < nt.  Step k:
+  //   consumers: conv2 of tile k-2 (y1 buffer k&1), then the patch of tile k (bytes requested
+  //              one step ago) into patch buffer k&1, then the request for tile k+1;
+  //   producers: conv1 of tile k-1 (patch buffer (k-1)&1 -> y1 buffer (k-1)&1).
+  // The barrier that ends a step orders every buffer hand-over (and, in step 0, the tables).
+  // The two kinds run separate loops with the same number of barriers, so that the second
+  // filter's registers are live only in the consumers' code.
+  const int nt = (a.total_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+  Tile tk = decode(blockIdx.x), tk1 = advance(tk), tm1 = tk, tm2 = tk;
+  if (consumer) {
+    // conv2 weights: this wave's 32 output channels, in registers for good.
+    // A-row r of tile nj is channel 32*ch + 8*(r>>2) + 4*nj + (r&3): lane group g then holds
+    // the 8 consecutive channels 32*ch + 8*g .. +7 of its pixel.
+    uint4 w2f[9][KS1][2];
 #pragma unroll
-    for (int t = 0; t < PGW; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) acc2[t][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const char* rowp = y1 + (size_t)(2 * pp * PGW) * (kS2Y1W * PXB);
+      for (int kh = 0; kh < KS1; ++kh)
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int kh = 0; kh < KS1; ++kh)
-#pragma unroll
-          for (int t = 0; t < PGW; ++t) {
-            const uint4 b = *reinterpret_cast<const uint4*>(rowp + ((2 * t + r) * kS2Y1W) * PXB + roff[s][kh]);
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj)
-              acc2[t][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8_t, w2f[r * 3 + s][kh][nj]), __builtin_bit_cast(bf16x8_t, b),
-                  acc2[t][nj], 0, 0, 0);
-          }
-    // lane (p, g): channels 32*ch + 8*g .. +7 of pixel (row, p)
-    const int ow = now.tx * kS2TW + p;
-    const float4 c0 = *reinterpret_cast<const float4*>(lb2 + 32 * ch + 8 * g);
-    const float4 c1 = *reinterpret_cast<const float4*>(lb2 + 32 * ch + 8 * g + 4);
-#pragma unroll
-    for (int t = 0; t < PGW; ++t) {
-      const int oh = now.ty * TH2 + pp * PGW + t;
-      if (oh < a.H2 && ow < a.W2) {
-        const float v[8] = {acc2[t][0][0] + c0.x, acc2[t][0][1] + c0.y, acc2[t][0][2] + c0.z, acc2[t][0][3] + c0.w,
-                            acc2[t][1][0] + c1.x, acc2[t][1][1] + c1.y, acc2[t][1][2] + c1.z, acc2[t][1][3] + c1.w};
-        unsigned o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          o[e] = pack_bf16x2(__builtin_amdgcn_fmed3f(v[2 * e], lo2, hi2),
-                             __builtin_amdgcn_fmed3f(v[2 * e + 1], lo2, hi2));
-        bf16_t* dst = reinterpret_cast<bf16_t*>(a.y) +
-                      (((size_t)now.n * a.H2 + oh) * a.W2 + ow) * a.y_ld + 32 * ch + 8 * g;
-        *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        for (int nj = 0; nj < 2; ++nj) {
+          const int co = 32 * ch + 8 * (p >> 2) + 4 * nj + (p & 3);
+          w2f[t][kh][nj] = *reinterpret_cast<const uint4*>(
+              reinterpret_cast<const bf16_t*>(a.w2) + (size_t)co * a.w2_kpad + t * (32 * KS1) + kh * 32 + 8 * g);
+        }
+    auto conv2 = [&](const Tile& now, const char* y1) {
+      f32x4 acc2[PGW][2];
+  #pragma unroll
+      for (int t = 0; t < PGW; ++t)
+  #pragma unroll
+        for (int nj = 0; nj < 2; ++nj) acc2[t][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // B operand number i = ((r*3 + s)*KS1 + kh)*PGW + t.  RING of them are kept in flight
+      // (reads the compiler does not wait for), so that the LDS latency hides behind the MFMAs
+      // of earlier operands.
+      constexpr int NB2 = 9 * KS1 * PGW, RING = NB2 < 8 ? NB2 : 8;
+      const unsigned y1_lds = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)y1 +
+                              (unsigned)((2 * pp * PGW) * (kS2Y1W * PXB));
+      unsigned baddr[3][KS1];
+  #pragma unroll
+      for (int sc = 0; sc < 3; ++sc)
+  #pragma unroll
+        for (int kh = 0; kh < KS1; ++kh) baddr[sc][kh] = y1_lds + (unsigned)roff[sc][kh];
+      u32x4_t ring[RING];
+      auto issue = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int t = i % PGW, kh = (i / PGW) % KS1, rs = i / (PGW * KS1);
+        lds_read16_async<((2 * t + rs / 3) * kS2Y1W) * PXB>(ring[i % RING], baddr[rs % 3][kh]);
+      };
+      auto step = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int t = i % PGW, kh = (i / PGW) % KS1, rs = i / (PGW * KS1);
+        constexpr int younger = (i + RING - 1 < NB2 - 1 ? i + RING - 1 : NB2 - 1) - i;
+        lds_wait<younger>(ring[i % RING]);
+        const u32x4_t b = ring[i % RING];
+  #pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+          acc2[t][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8_t, w2f[rs][kh][nj]), __builtin_bit_cast(bf16x8_t, b), acc2[t][nj], 0, 0, 0);
+        if constexpr (i + RING < NB2) issue(std::integral_constant<int, i + RING>{});
+      };
+      static_for<0, RING>(issue);
+      static_for<0, NB2>(step);
+      // lane (p, g): channels 32*ch + 8*g .. +7 of pixel (row, p)
+      const int ow = now.tx * kS2TW + p;
+      const float4 c0 = *reinterpret_cast<const float4*>(lb2 + 32 * ch + 8 * g);
+      const float4 c1 = *reinterpret_cast<const float4*>(lb2 + 32 * ch + 8 * g + 4);
+  #pragma unroll
+      for (int t = 0; t < PGW; ++t) {
+        const int oh = now.ty * TH2 + pp * PGW + t;
+        if (oh < a.H2 && ow < a.W2) {
+          const float v[8] = {acc2[t][0][0] + c0.x, acc2[t][0][1] + c0.y, acc2[t][0][2] + c0.z, acc2[t][0][3] + c0.w,
+                              acc2[t][1][0] + c1.x, acc2[t][1][1] + c1.y, acc2[t][1][2] + c1.z, acc2[t][1][3] + c1.w};
+          unsigned o[4];
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = pack_bf16x2(__builtin_amdgcn_fmed3f(v[2 * e], lo2, hi2),
+                               __builtin_amdgcn_fmed3f(v[2 * e + 1], lo2, hi2));
+          bf16_t* dst = reinterpret_cast<bf16_t*>(a.y) +
+                        (((size_t)now.n * a.H2 + oh) * a.W2 + ow) * a.y_ld + 32 * ch + 8 * g;
+          *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
       }
+    };
+
+    unsigned ureg[FS];
+    fetch(tk, ureg);
+    for (int k = 0; k < nt + 2; ++k) {
+      if (k >= 2) conv2(tm2, y10 + (k & 1) * L::Y1_BYTES);
+      if (k < nt) commit(tk, ureg, patch0 + (k & 1) * L::PATCH_BYTES);
+      if (k + 1 < nt) fetch(tk1, ureg);
+      __builtin_amdgcn_s_barrier();
+      tm2 = tm1; tm1 = tk; tk = tk1; tk1 = advance(tk1);
+    }
+  } else {
+    for (int k = 0; k < nt + 2; ++k) {
+      if (k >= 1 && k <= nt)
+        conv1(tm1, patch0 + ((k - 1) & 1) * L::PATCH_BYTES, y10 + ((k - 1) & 1) * L::Y1_BYTES);
+      __builtin_amdgcn_s_barrier();
+      tm1 = tk; tk = tk1; tk1 = advance(tk1);
     }
   }
 }
@@ -451,13 +535,13 @@ static int launch_stem2(const Stem2Args& a0, hipStream_t stream) {
       set_error("fss_stem2_conv_u8: cannot query the device");
       return 1;
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NW * 64,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 2 * NW * 64,
                                                      smem) != hipSuccess || per_cu < 1)
       per_cu = 1;
     num_cu = prop.multiProcessorCount;
   }
   const int blocks = std::min(a.total_tiles, num_cu * per_cu);
-  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(2 * NW * 64), smem, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error(std::string("fss_stem2_conv_u8 launch: ") + hipGetErrorString(e));
@@ -512,7 +596,7 @@ extern "C" int fss_stem2_conv_u8(const uint8_t* x, const void* w1_packed, const 
   for (int i = 0; i < 3; ++i) { a.mean[i] = mean3[i]; a.scale[i] = scale3[i]; }
   a.unit_scale = scale3[0] == 1.f && scale3[1] == 1.f && scale3[2] == 1.f;
   hipStream_t s = (hipStream_t)stream;
-  // tiles of 4 x 16 output pixels, 4 waves: two blocks share a CU
+  // tiles of 4 x 16 output pixels, 4 + 4 waves: one block per CU
   switch ((c1 / 32) * 10 + c2 / 32) {
     case 11: return launch_stem2<1, 1, 4, 4>(a, s);
     case 12: return launch_stem2<1, 2, 4, 4>(a, s);
