@@ -433,64 +433,155 @@ __global__ void upsample_argmax_kernel(const float* __restrict__ x, uint8_t* __r
   labels[idx] = (uint8_t)arg;
 }
 
-// Power-of-two align_corners zoom Z (out = (in-1)*Z + 1): one thread per INPUT
-// cell computes the Z x Z output pixels whose top-left neighbour it is, reading
-// its 2x2 neighbourhood once, 4 channels per 16-byte load.  Source coordinates
-// are exact here (scale = 1/Z), so lerp weights are (i/Z, j/Z).
-template <int Z>
-__global__ void upsample_argmax_zoom_kernel(const float* __restrict__ x,
-                                            uint8_t* __restrict__ labels, int N, int H, int W,
-                                            int C, int x_ld, int Ho, int Wo) {
-  const size_t total = (size_t)N * H * W;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  size_t p = idx;
-  const int x0 = (int)(p % W); p /= W;
-  const int y0 = (int)(p % H);
-  const int n = (int)(p / H);
-  const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-  const float* b = x + (size_t)n * H * W * x_ld;
-  const float4* ptl = reinterpret_cast<const float4*>(b + ((size_t)y0 * W + x0) * x_ld);
-  const float4* ptr = reinterpret_cast<const float4*>(b + ((size_t)y0 * W + x1) * x_ld);
-  const float4* pbl = reinterpret_cast<const float4*>(b + ((size_t)y1 * W + x0) * x_ld);
-  const float4* pbr = reinterpret_cast<const float4*>(b + ((size_t)y1 * W + x1) * x_ld);
-  float best[Z][Z];
-  int arg[Z][Z];
+// Power-of-two align_corners zoom Z (out = (in-1)*Z + 1).  A block owns a tile of
+// kZoomTX x kZoomTY INPUT cells; the thread of a cell produces the Z x Z output pixels whose
+// top-left neighbour the cell is.  Source coordinates are exact here (scale = 1/Z), so the
+// lerp weights are (i/Z, j/Z).
+//
+// Most cells never interpolate: if the four corner pixels of a cell have the same argmax k,
+// every pixel inside has it too (for c < k all four corners have l_c < l_k, for c > k
+// l_c <= l_k, and a bilinear blend is a convex combination, so k stays the first maximum).
+// Pass 1 computes the argmax of every input pixel of the tile (+ one halo row and column)
+// into LDS; cells with four equal corners store their label block at once, the others are
+// queued in LDS and pass 2 hands them out densely, so that waves do not idle beside a few
+// slow lanes.
+constexpr int kZoomTX = 32, kZoomTY = 8;
+
+template <int Z> struct ZoomOut {
+  // stores the Z labels of one output row of a cell (4 per unaligned dword store)
+  static __device__ __forceinline__ void row(uint8_t* dst, const int (&l)[Z], int valid) {
+    if (valid >= Z) {
 #pragma unroll
-  for (int i = 0; i < Z; ++i)
+      for (int j = 0; j < Z; j += 4) {
+        if constexpr (Z >= 4) {
+          *reinterpret_cast<unsigned*>(dst + j) =
+              (unsigned)l[j] | ((unsigned)l[j + 1] << 8) | ((unsigned)l[j + 2] << 16) | ((unsigned)l[j + 3] << 24);
+        } else {
+          *reinterpret_cast<unsigned short*>(dst + j) = (unsigned short)((unsigned)l[j] | ((unsigned)l[j + 1] << 8));
+        }
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < Z; ++j) { best[i][j] = -INFINITY; arg[i][j] = 0; }
+      for (int j = 0; j < Z; ++j)
+        if (j < valid) dst[j] = (uint8_t)l[j];
+    }
+  }
+};
+
+__device__ __forceinline__ int pixel_argmax(const float* __restrict__ px, int C) {
+  const float4* p4 = reinterpret_cast<const float4*>(px);
+  float best = -INFINITY;
+  int arg = 0;
   const int groups = (C + 3) >> 2;
   for (int g = 0; g < groups; ++g) {
-    const float4 tl4 = ptl[g], tr4 = ptr[g], bl4 = pbl[g], br4 = pbr[g];
-    const float tl[4] = {tl4.x, tl4.y, tl4.z, tl4.w}, tr[4] = {tr4.x, tr4.y, tr4.z, tr4.w};
-    const float bl[4] = {bl4.x, bl4.y, bl4.z, bl4.w}, br[4] = {br4.x, br4.y, br4.z, br4.w};
+    const float4 v4 = p4[g];
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int c = g * 4 + e;
-      if (c < C) {
+      if (c < C && (v[e] > best || c == 0)) { best = v[e]; arg = c; }
+    }
+  }
+  return arg;
+}
+
+template <int Z>
+__global__ void __launch_bounds__(kZoomTX * kZoomTY)
+upsample_argmax_zoom_kernel(const float* __restrict__ x, uint8_t* __restrict__ labels, int N, int H,
+                            int W, int C, int x_ld, int Ho, int Wo, int tiles_x, int tiles_y) {
+  constexpr int NTH = kZoomTX * kZoomTY;
+  __shared__ uint8_t amax[kZoomTY + 1][kZoomTX + 4];
+  __shared__ unsigned short queue[NTH];
+  __shared__ int qcount;
+  const int tid = threadIdx.x;
+  int tile = blockIdx.x;
+  const int tx = tile % tiles_x; tile /= tiles_x;
+  const int ty = tile % tiles_y;
+  const int n = tile / tiles_y;
+  const float* b = x + (size_t)n * H * W * x_ld;
+  const int cx = tx * kZoomTX, cy = ty * kZoomTY;
+
+  // ---- pass 1: argmax of the tile's pixels and of the halo column / row (clamped to the image:
+  // the same clamping the interpolation applies to x0 + 1, y0 + 1)
+  {
+    const int lx = tid % kZoomTX, ly = tid / kZoomTX;
+    amax[ly][lx] = (uint8_t)pixel_argmax(b + ((size_t)min(cy + ly, H - 1) * W + min(cx + lx, W - 1)) * x_ld, C);
+    if (tid < kZoomTY + 1 + kZoomTX) {
+      const int hy = tid <= kZoomTY ? tid : kZoomTY, hx = tid <= kZoomTY ? kZoomTX : tid - (kZoomTY + 1);
+      amax[hy][hx] = (uint8_t)pixel_argmax(b + ((size_t)min(cy + hy, H - 1) * W + min(cx + hx, W - 1)) * x_ld, C);
+    }
+    if (tid == 0) qcount = 0;
+  }
+  __syncthreads();
+
+  // Z x Z labels of cell (y0, x0) -> output
+  auto store_cell = [&](int y0, int x0, const int (&arg)[Z][Z]) {
+    const int cols = min(Z, Wo - x0 * Z);
 #pragma unroll
-        for (int j = 0; j < Z; ++j) {
-          const float lx = (float)j * (1.0f / Z);
-          const float top = tl[e] + (tr[e] - tl[e]) * lx;
-          const float bot = bl[e] + (br[e] - bl[e]) * lx;
+    for (int i = 0; i < Z; ++i) {
+      const int oh = y0 * Z + i;
+      if (oh < Ho) ZoomOut<Z>::row(labels + ((size_t)n * Ho + oh) * Wo + (size_t)x0 * Z, arg[i], cols);
+    }
+  };
+  {
+    const int lx = tid % kZoomTX, ly = tid / kZoomTX;
+    const int x0 = cx + lx, y0 = cy + ly;
+    if (x0 < W && y0 < H) {
+      const int a00 = amax[ly][lx], a01 = amax[ly][lx + 1], a10 = amax[ly + 1][lx], a11 = amax[ly + 1][lx + 1];
+      if (a00 == a01 && a00 == a10 && a00 == a11) {
+        int arg[Z][Z];
 #pragma unroll
-          for (int i = 0; i < Z; ++i) {
-            const float v = top + (bot - top) * ((float)i * (1.0f / Z));
-            if (v > best[i][j] || c == 0) { best[i][j] = v; arg[i][j] = c; }
+        for (int i = 0; i < Z; ++i)
+#pragma unroll
+          for (int j = 0; j < Z; ++j) arg[i][j] = a00;
+        store_cell(y0, x0, arg);
+      } else {
+        queue[atomicAdd(&qcount, 1)] = (unsigned short)tid;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 2: the cells that need the interpolation
+  const int nq = qcount;
+  for (int q = tid; q < nq; q += NTH) {
+    const int cell = queue[q];
+    const int x0 = cx + cell % kZoomTX, y0 = cy + cell / kZoomTX;
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+    const float4* ptl = reinterpret_cast<const float4*>(b + ((size_t)y0 * W + x0) * x_ld);
+    const float4* ptr = reinterpret_cast<const float4*>(b + ((size_t)y0 * W + x1) * x_ld);
+    const float4* pbl = reinterpret_cast<const float4*>(b + ((size_t)y1 * W + x0) * x_ld);
+    const float4* pbr = reinterpret_cast<const float4*>(b + ((size_t)y1 * W + x1) * x_ld);
+    float best[Z][Z];
+    int arg[Z][Z];
+#pragma unroll
+    for (int i = 0; i < Z; ++i)
+#pragma unroll
+      for (int j = 0; j < Z; ++j) { best[i][j] = -INFINITY; arg[i][j] = 0; }
+    const int groups = (C + 3) >> 2;
+    for (int g = 0; g < groups; ++g) {
+      const float4 tl4 = ptl[g], tr4 = ptr[g], bl4 = pbl[g], br4 = pbr[g];
+      const float tl[4] = {tl4.x, tl4.y, tl4.z, tl4.w}, tr[4] = {tr4.x, tr4.y, tr4.z, tr4.w};
+      const float bl[4] = {bl4.x, bl4.y, bl4.z, bl4.w}, br[4] = {br4.x, br4.y, br4.z, br4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = g * 4 + e;
+        if (c < C) {
+#pragma unroll
+          for (int j = 0; j < Z; ++j) {
+            const float lx = (float)j * (1.0f / Z);
+            const float top = tl[e] + (tr[e] - tl[e]) * lx;
+            const float bot = bl[e] + (br[e] - bl[e]) * lx;
+#pragma unroll
+            for (int i = 0; i < Z; ++i) {
+              const float v = top + (bot - top) * ((float)i * (1.0f / Z));
+              if (v > best[i][j] || c == 0) { best[i][j] = v; arg[i][j] = c; }
+            }
           }
         }
       }
     }
-  }
-#pragma unroll
-  for (int i = 0; i < Z; ++i) {
-    const int oh = y0 * Z + i;
-    if (oh >= Ho) break;
-    uint8_t* row = labels + ((size_t)n * Ho + oh) * Wo + (size_t)x0 * Z;
-#pragma unroll
-    for (int j = 0; j < Z; ++j)
-      if (x0 * Z + j < Wo) row[j] = (uint8_t)arg[i][j];
+    store_cell(y0, x0, arg);
   }
 }
 
@@ -852,10 +943,12 @@ int fss_upsample_argmax(const float* logits, uint8_t* labels, float* logits_out,
                     (wo - 1) == zw * (wd - 1);
   if (pow2 && logits_out == nullptr && (x_ld & 3) == 0 && ((c + 3) & ~3) <= x_ld &&
       ((uintptr_t)logits & 15) == 0) {
-    const size_t cells = (size_t)n * h * wd;
-#define FSS_ZOOM(Z)                                                                              \
-  hipLaunchKernelGGL(upsample_argmax_zoom_kernel<Z>, dim3(grid_for(cells)), dim3(kBlock), 0, s, \
-                     logits, labels, n, h, wd, c, x_ld, ho, wo)
+    const int tiles_x = ceil_div(wd, kZoomTX), tiles_y = ceil_div(h, kZoomTY);
+    const long long tiles = (long long)tiles_x * tiles_y * n;
+    FSS_REQUIRE(tiles < 0x7fffffffLL, "too many tiles");
+#define FSS_ZOOM(Z)                                                                                \
+  hipLaunchKernelGGL(upsample_argmax_zoom_kernel<Z>, dim3((unsigned)tiles), dim3(kZoomTX * kZoomTY), 0, s, \
+                     logits, labels, n, h, wd, c, x_ld, ho, wo, tiles_x, tiles_y)
     if (zh == 2) FSS_ZOOM(2); else if (zh == 4) FSS_ZOOM(4); else FSS_ZOOM(8);
 #undef FSS_ZOOM
     FSS_LAUNCH_CHECK();

@@ -493,6 +493,31 @@ def test_upsample_argmax_lut_confusion():
         assert gz.max() < c
         assert np.array_equal(gz[clearz], O.argmax_channels(upz)[clearz])
         assert clearz.mean() > 0.4
+    # smooth logits (large regions with one winning class): most cells take the kernel's
+    # shortcut "four corners agree => the whole cell has that label"; the result must still
+    # be the oracle's argmax of the interpolated logits
+    hs, ws = 19, 45
+    coarse = rng.normal(0, 1, (n, 3, 4, c)).astype(np.float32)
+    xs = O.resize_bilinear(coarse, hs, ws, True) * 4 + rng.normal(0, 0.01, (n, hs, ws, c)).astype(np.float32)
+    xs = xs.astype(np.float32)
+    xsp = np.zeros((n, hs, ws, 20), np.float32)
+    xsp[..., :c] = xs
+    xsp[..., c] = 1e9
+    xsd = torch.from_numpy(xsp).cuda()
+    for z in (2, 4, 8):
+        hz, wz = (hs - 1) * z + 1, (ws - 1) * z + 1
+        upz = O.resize_bilinear(xs, hz, wz, True)
+        labz = torch.full((n, hz, wz), 255, dtype=torch.uint8, device='cuda')
+        _call('fss_upsample_argmax', xsd.data_ptr(), labz.data_ptr(), None, n, hs, ws, c, 20, hz, wz, None)
+        gz = labz.cpu().numpy().astype(np.int64)
+        sz = np.sort(upz, axis=3)
+        clearz = (sz[..., -1] - sz[..., -2]) > 1e-5
+        assert np.array_equal(gz[clearz], O.argmax_channels(upz)[clearz])
+        assert clearz.mean() > 0.95
+        am = O.argmax_channels(xs)
+        uniform = (am[:, :-1, :-1] == am[:, 1:, :-1]) & (am[:, :-1, :-1] == am[:, :-1, 1:]) & \
+                  (am[:, :-1, :-1] == am[:, 1:, 1:])
+        assert 0.5 < uniform.mean() < 1.0        # both kinds of cells are present
     # colour LUT with crop
     from libs.constants import CITYSCAPES_LABEL_COLORS, CITYSCAPES_LABEL_IDS
     for table in (CITYSCAPES_LABEL_COLORS, CITYSCAPES_LABEL_IDS):
