@@ -686,6 +686,84 @@ __global__ void dwconv_kernel(const T* __restrict__ x, const float* __restrict__
   o.store(y + idx * E);
 }
 
+// 3x3 depthwise convolution, one thread per 16-byte channel chunk and run of R output
+// pixels of one row: the 9 x E filter taps of the chunk stay in registers, and every input
+// chunk the run touches is loaded and unpacked once and used by all the outputs it feeds
+// (stride 1: R + 2*DIL columns per filter row instead of 3*R).
+template <typename T, int STRIDE, int DIL, int R>
+__global__ void dwconv3x3_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                 const float* __restrict__ bias, T* __restrict__ y, int N, int H, int W,
+                                 int C, int pad_t, int pad_l, int Ho, int Wo, int runs, int act) {
+  constexpr int E = Chunk<T>::N;
+  constexpr int COLS = (R - 1) * STRIDE + 2 * DIL + 1;   // input columns under one filter row
+  const int cc = C / E;
+  const size_t total = (size_t)N * Ho * runs * cc;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % cc);
+  size_t p = idx / cc;
+  const int run = (int)(p % runs); p /= runs;
+  const int oh = (int)(p % Ho);
+  const int n = (int)(p / Ho);
+  const int ow0 = run * R;
+  float wt[9][E];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+      const float4 w4 = *reinterpret_cast<const float4*>(w + (size_t)t * C + ch * E + e);
+      wt[t][e] = w4.x; wt[t][e + 1] = w4.y; wt[t][e + 2] = w4.z; wt[t][e + 3] = w4.w;
+    }
+  float acc[R][E];
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[j][e] = 0.f;
+  const int iw0 = ow0 * STRIDE - pad_l;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int ih = oh * STRIDE - pad_t + r * DIL;
+    if ((unsigned)ih >= (unsigned)H) continue;
+    const T* row = x + (((size_t)n * H + ih) * W) * C + ch * E;
+#pragma unroll
+    for (int t = 0; t < COLS; ++t) {
+      // does any output of the run read column t of this filter row?
+      bool used = false;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int num = t - s * DIL;
+        if (num >= 0 && num % STRIDE == 0 && num / STRIDE < R) used = true;
+      }
+      if (!used) continue;
+      const int iw = iw0 + t;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      Chunk<T> v;
+      v.load(row + (size_t)iw * C);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int num = t - s * DIL;
+        if (num >= 0 && num % STRIDE == 0 && num / STRIDE < R) {
+          const int j = num / STRIDE;
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[j][e] = fmaf(v.v[e], wt[r * 3 + s][e], acc[j][e]);
+        }
+      }
+    }
+  }
+  float b[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) b[e] = bias ? bias[ch * E + e] : 0.f;
+  T* out = y + ((((size_t)n * Ho + oh) * Wo + ow0) * C) + ch * E;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (ow0 + j >= Wo) break;
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < E; ++e) o.v[e] = apply_act(acc[j][e] + b[e], act);
+    o.store(out + (size_t)j * C);
+  }
+}
+
 }  // namespace fss
 
 using namespace fss;
@@ -1000,8 +1078,32 @@ int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y,
   FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0, "bad shape");
   FSS_REQUIRE(kh > 0 && kw > 0 && stride > 0 && dilation > 0 && pad_top >= 0 && pad_left >= 0,
               "bad filter");
-  const size_t total = (size_t)n * ho * wo * (c / (dtype == FSS_F32 ? 4 : 8));
   hipStream_t s = (hipStream_t)stream;
+  // 3x3 with the strides / dilations the MobileNet backbones use: the register-blocked kernel
+  // (small problems keep one thread per output chunk: more threads fill the chip better)
+  constexpr int R = 4;
+  const int runs = ceil_div(wo, R);
+  const size_t threads = (size_t)n * ho * runs * (c / (dtype == FSS_F32 ? 4 : 8));
+  if (kh == 3 && kw == 3 && ((uintptr_t)w & 15) == 0 && threads >= 300000) {
+#define FSS_DW(T, ST, DL)                                                                            \
+  hipLaunchKernelGGL((dwconv3x3_kernel<T, ST, DL, R>), dim3(grid_for(threads)), dim3(kBlock), 0, s,  \
+                     (const T*)x, w, bias, (T*)y, n, h, wd, c, pad_top, pad_left, ho, wo, runs, act)
+#define FSS_DW_ANY(T)                                                  \
+  if (stride == 1 && dilation == 1) { FSS_DW(T, 1, 1); }               \
+  else if (stride == 1 && dilation == 2) { FSS_DW(T, 1, 2); }          \
+  else if (stride == 1 && dilation == 4) { FSS_DW(T, 1, 4); }          \
+  else if (stride == 2 && dilation == 1) { FSS_DW(T, 2, 1); }          \
+  else handled = false;
+    bool handled = true;
+    if (dtype == FSS_F32) { FSS_DW_ANY(float) } else { FSS_DW_ANY(bf16_t) }
+#undef FSS_DW_ANY
+#undef FSS_DW
+    if (handled) {
+      FSS_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  const size_t total = (size_t)n * ho * wo * (c / (dtype == FSS_F32 ? 4 : 8));
   if (dtype == FSS_F32)
     hipLaunchKernelGGL(dwconv_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const float*)x, w, bias, (float*)y, n, h, wd, c, kh, kw, stride, dilation,

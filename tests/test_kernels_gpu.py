@@ -289,8 +289,13 @@ def _call(name, *args):
 def test_depthwise(dt):
     gu, L = _gu(), _lib()
     rng = np.random.default_rng(3)
-    for (n, h, wd, c, stride, rate) in [(1, 33, 65, 96, 1, 4), (2, 20, 26, 24, 2, 1),
-                                        (1, 17, 33, 144, 1, 2), (1, 9, 11, 32, 2, 1)]:
+    # (the large cases run the register-blocked 3x3 kernel, the small ones the generic kernel)
+    for (n, h, wd, c, stride, rate) in [(8, 129, 257, 96, 1, 4), (12, 200, 258, 64, 2, 1),
+                                        (8, 130, 259, 144, 1, 2), (8, 120, 163, 80, 1, 1),
+                                        (1, 33, 65, 96, 1, 4), (2, 20, 26, 24, 2, 1),
+                                        (1, 17, 33, 144, 1, 2), (1, 9, 11, 32, 2, 1),
+                                        (2, 12, 19, 40, 1, 1),       # plain 3x3, ragged run at the row end
+                                        (1, 15, 22, 16, 1, 3)]:      # a dilation only the generic kernel has
         x = rng.normal(0, 1, (n, h, wd, c)).astype(np.float32)
         w = rng.normal(0, 0.4, (3, 3, c, 1)).astype(np.float32)
         bias = rng.normal(0, 0.5, c).astype(np.float32)
