@@ -24,6 +24,11 @@
 // v_mfma_f32_32x32x2_f32, with the same k permutation on both operands) for
 // float.
 //
+// Two-input form: y = act(conv(x, W) + conv1x1(x2, W2) + bias).  The K axis is the taps of
+// the first filter followed by the cin2 channels of the second input, whose A rows are the
+// pixels of x2 themselves ("one more tap" in the scalar tap walk); used for the cascade
+// feature fusion, where the sum of two convolutions is needed and neither alone.
+//
 // Epilogue: each wave transposes its accumulators through LDS (32 rows at a
 // time) so that bias / residual / activation run on, and the stores write,
 // 16-byte row-contiguous pieces (whole 128-byte lines per row segment), with an
@@ -43,11 +48,13 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4] = {0u, 0u, 
 
 struct ConvArgs {
   const void* x;
+  const void* x2;   // second input (1x1, stride 1, the output's spatial size), or null
   const void* w;
   const float* bias;
   const void* res;
   void* y;
   int N, H, W, Cin, Cout, KH, KW, stride, dil, pad_t, pad_l, Ho, Wo, act;
+  int Cin2;         // channels of x2: its K segment follows the filter taps in the packed weights
   int M, K, Kpad, y_ld, res_ld, tiles_m, tiles_n;
 };
 
@@ -216,8 +223,15 @@ conv_igemm_kernel(const ConvArgs a) {
                           ((unsigned)(iw0[i] + sx * a.dil) < (unsigned)a.W);
           tapmask[i] |= (unsigned long long)ok << t;
         }
+      // the second input counts as tap number KH*KW: real for every row of the matrix
+      if (a.Cin2 > 0) tapmask[i] |= (unsigned long long)row_ok << (a.KH * a.KW);
     }
   }
+  // second input: byte offset of this lane's chunk in row (tile_m*BM + row0) of x2; the rows
+  // of one lane are RSTEP pixels apart (fits 32 bits: checked by the host)
+  const char* x2c = reinterpret_cast<const char*>(a.x2);
+  const unsigned r2off0 = (unsigned)(((long long)(tile_m * BM + row0) * a.Cin2 + chunk * EPC) * (long long)sizeof(T));
+  const unsigned r2step = (unsigned)(RSTEP * a.Cin2 * (int)sizeof(T));
   const char* wptr[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i)
@@ -236,7 +250,7 @@ conv_igemm_kernel(const ConvArgs a) {
     unsigned long long mine = 0;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) mine |= tapmask[i];
-    const int ntaps = a.KH * a.KW;
+    const int ntaps = a.KH * a.KW + (a.Cin2 > 0 ? 1 : 0);
     unsigned long long wmask = 0;
     for (int t = 0; t < ntaps; ++t)
       if (__ballot((mine >> t) & 1ull) != 0ull) wmask |= 1ull << t;
@@ -246,7 +260,7 @@ conv_igemm_kernel(const ConvArgs a) {
     for (int w = 0; w < WAVES_M * WAVES_N; ++w) bmask |= wave_taps[w];
     bmask = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(bmask >> 32)) << 32) |
             (unsigned)__builtin_amdgcn_readfirstlane((unsigned)bmask);
-    KT = __popcll(bmask) * (a.Cin / BK);
+    KT = __popcll(bmask & ((1ull << (a.KH * a.KW)) - 1ull)) * (a.Cin / BK) + a.Cin2 / BK;
     while (tap < ntaps && !((bmask >> tap) & 1ull)) {
       ++tap;
       if (++ks == a.KW) { ks = 0; ++kr; }
@@ -267,10 +281,13 @@ conv_igemm_kernel(const ConvArgs a) {
       const int tbit = min(tap, 63);                    // bit 63 is never set
       // byte offset of the tap inside one image: fits 32 bits (checked by the host)
       const int tap_off = ((kr * a.dil * a.W + ks * a.dil) * a.Cin + kc) * (int)sizeof(T);
+      const bool second = a.Cin2 > 0 && tap == a.KH * a.KW;          // uniform
+      const unsigned off2 = r2off0 + (unsigned)(kc * (int)sizeof(T));
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const bool ok = (tapmask[i] >> tbit) & 1ull;
-        const void* src = ok ? (const void*)(rptr[i] + tap_off) : zero_src;
+        const char* real = second ? x2c + (off2 + i * r2step) : rptr[i] + tap_off;
+        const void* src = ok ? (const void*)real : zero_src;
         glds16(src, dstA + i * (NT * 16));
       }
     } else {
@@ -295,12 +312,13 @@ conv_igemm_kernel(const ConvArgs a) {
     }
     kc += BK;
     if constexpr (ALIGNED) {
-      if (kc == a.Cin) {
+      const int ntaps_all = a.KH * a.KW + (a.Cin2 > 0 ? 1 : 0);
+      if (kc == (tap == a.KH * a.KW ? a.Cin2 : a.Cin)) {
         kc = 0;
         do {
           ++tap;
           if (++ks == a.KW) { ks = 0; ++kr; }
-        } while (tap < a.KH * a.KW && !((bmask >> tap) & 1ull));
+        } while (tap < ntaps_all && !((bmask >> tap) & 1ull));
       }
     } else {
       while (kc >= a.Cin) {
@@ -515,8 +533,12 @@ static int launch_conv_impl(ConvArgs& a, hipStream_t stream) {
 template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE, int FM>
 static int launch_conv(ConvArgs& a, hipStream_t stream) {
   constexpr int BK = BKB / (int)sizeof(T);
-  if (a.Cin % BK == 0 && a.KH * a.KW <= 63)
+  if (a.Cin % BK == 0 && a.Cin2 % BK == 0 && a.KH * a.KW <= 62)
     return launch_conv_impl<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, FM, true>(a, stream);
+  if (a.Cin2 > 0) {
+    set_error("fss_conv2d_dual_nhwc: cin and cin2 must be multiples of the K tile");
+    return 2;
+  }
   return launch_conv_impl<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, FM, false>(a, stream);
 }
 
@@ -622,14 +644,16 @@ extern "C" int fss_conv_config_info(int config, int info[7]) {
   return 2;
 }
 
-extern "C" int fss_conv2d_nhwc(const fss_conv_desc* d, const void* x, const void* w_packed,
-                               const float* bias, const void* residual, void* y, void* stream) {
+extern "C" int fss_conv2d_dual_nhwc(const fss_conv_desc* d, const void* x, const void* x2, int cin2,
+                                    const void* w_packed, const float* bias, const void* residual,
+                                    void* y, void* stream) {
   FSS_REQUIRE(d && x && w_packed && y, "null argument");
   FSS_REQUIRE(d->in_dtype == FSS_F32 || d->in_dtype == FSS_BF16, "bad in_dtype");
   FSS_REQUIRE(d->out_dtype == FSS_F32 || d->out_dtype == FSS_BF16, "bad out_dtype");
   FSS_REQUIRE(!(d->in_dtype == FSS_F32 && d->out_dtype == FSS_BF16),
               "f32 input with bf16 output is not supported");
   const int epc = d->in_dtype == FSS_F32 ? 4 : 8;
+  const int esz = d->in_dtype == FSS_F32 ? 4 : 2;
   FSS_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "bad shape");
   FSS_REQUIRE(d->cin % epc == 0, "cin must be a multiple of 16 bytes of elements");
   FSS_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dilation > 0, "bad filter");
@@ -639,23 +663,31 @@ extern "C" int fss_conv2d_nhwc(const fss_conv_desc* d, const void* x, const void
   FSS_REQUIRE((long long)(d->ho - 1) * d->stride - d->pad_top < d->h &&
                   (long long)(d->wo - 1) * d->stride - d->pad_left < d->w,
               "output size exceeds the input");
-  int k_pad = 0, cout_pad = 0;
-  fss_conv_pack_dims(d->cin, d->kh, d->kw, d->cout, d->in_dtype, &k_pad, &cout_pad);
+  FSS_REQUIRE((x2 == nullptr) == (cin2 == 0) && cin2 >= 0, "x2 and cin2 go together");
+  if (cin2 > 0) {
+    FSS_REQUIRE(d->cin % 64 == 0 && cin2 % 64 == 0, "two-input form: cin and cin2 must be multiples of 64");
+    FSS_REQUIRE(((uintptr_t)x2 & 15) == 0, "unaligned pointer");
+    FSS_REQUIRE((long long)d->n * d->ho * d->wo * cin2 * esz < 0xffffffffLL,
+                "second input must be smaller than 4 GiB");
+  }
+  const int k = d->cin * d->kh * d->kw + cin2;
+  const int k_pad = (k + 63) / 64 * 64, cout_pad = (d->cout + 255) / 256 * 256;
   FSS_REQUIRE(d->k_pad == k_pad && d->cout_pad == cout_pad, "packed weight dims mismatch");
   FSS_REQUIRE(d->y_ld >= d->cout, "y_ld < cout");
   FSS_REQUIRE(residual == nullptr || d->res_ld >= d->cout, "res_ld < cout");
   FSS_REQUIRE((long long)d->n * d->ho * d->wo < 0x7fffffffLL, "too many output pixels");
-  FSS_REQUIRE((long long)d->h * d->w * d->cin * (d->in_dtype == FSS_F32 ? 4 : 2) < 0x7fffffffLL,
+  FSS_REQUIRE((long long)d->h * d->w * d->cin * esz < 0x7fffffffLL,
               "one input image must be smaller than 2 GiB");
   FSS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0, "unaligned pointer");
 
   ConvArgs a;
-  a.x = x; a.w = w_packed; a.bias = bias; a.res = residual; a.y = y;
+  a.x = x; a.x2 = x2; a.w = w_packed; a.bias = bias; a.res = residual; a.y = y;
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout;
   a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.dil = d->dilation;
   a.pad_t = d->pad_top; a.pad_l = d->pad_left; a.Ho = d->ho; a.Wo = d->wo; a.act = d->act;
+  a.Cin2 = cin2;
   a.M = d->n * d->ho * d->wo;
-  a.K = d->cin * d->kh * d->kw;
+  a.K = k;
   a.Kpad = k_pad; a.y_ld = d->y_ld; a.res_ld = d->res_ld;
   a.tiles_m = a.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
@@ -663,4 +695,9 @@ extern "C" int fss_conv2d_nhwc(const fss_conv_desc* d, const void* x, const void
   if (d->in_dtype == FSS_F32) return dispatch_conv<float, float>(a, d->config, s);
   if (d->out_dtype == FSS_BF16) return dispatch_conv<bf16_t, bf16_t>(a, d->config, s);
   return dispatch_conv<bf16_t, float>(a, d->config, s);
+}
+
+extern "C" int fss_conv2d_nhwc(const fss_conv_desc* d, const void* x, const void* w_packed,
+                               const float* bias, const void* residual, void* y, void* stream) {
+  return fss_conv2d_dual_nhwc(d, x, nullptr, 0, w_packed, bias, residual, y, stream);
 }

@@ -91,7 +91,7 @@ class Step(object):
 # index of the output-pointer arguments of every kernel entry point (everything else
 # that points into an activation buffer is read)
 _OUT_ARGS = {
-    'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,),
+    'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,), 'fss_conv2d_dual_nhwc': (7,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
     'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1,), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
     'fss_add_act': (2,), 'fss_copy_channels': (2,), 'fss_upsample_argmax': (1, 2),
@@ -108,7 +108,7 @@ class CompiledGraph(object):
 
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
-                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True):
+                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
@@ -132,6 +132,8 @@ class CompiledGraph(object):
         self.fuse_stem = fuse_stem
         self.fuse_pyramid_pool = fuse_pyramid_pool
         self.fuse_stem2 = fuse_stem2
+        self.fuse_dual = fuse_dual
+        self.dual = {}          # 1x1 conv node -> the conv whose output it is added to (one launch)
         self.two_streams = False
         self.release_after = None
         self.events = []
@@ -426,11 +428,87 @@ class CompiledGraph(object):
                    nbytes=n * (hr // sub) * (wr // sub) * 3 + n * h2 * w2 * c2 * _ESZ[self.dt],
                    keep=(mean, sc))
 
+    def _dual_partner(self, ln):
+        """The 1x1 convolution A when `relu?(conv ln + A)` can run as one
+        fss_conv2d_dual_nhwc launch (the cascade feature fusion): both without bias and
+        activation, stride 1, the add their only consumer, A later in the order with its
+        input already computable, channel counts multiples of 64."""
+        a = ln.attrs
+        if not self.fuse_dual or a['biases'] is not None or a['activation'] is not None or a['stride'] != 1:
+            return None
+        add = self._only_consumer(ln, 'add')
+        if add is None or len(add.inputs) != 2:
+            return None
+        A = add.inputs[0] if add.inputs[1] is ln else add.inputs[1]
+        if A is ln or A.kind != 'conv2d' or A.pos < ln.pos or self._only_consumer(A, 'add') is not add:
+            return None
+        b = A.attrs
+        if ((b['kh'], b['kw'], b['stride'], b['rate']) != (1, 1, 1, 1) or b['biases'] is not None
+                or b['activation'] is not None or A.shape != ln.shape or A.inputs[0].pos > ln.pos):
+            return None
+        if ln.inputs[0].shape[3] % 64 or A.inputs[0].shape[3] % 64:
+            return None
+        return A
+
+    def _l_conv_dual(self, A, B):
+        """relu?(conv B + conv1x1 A) in one launch; A is the node being lowered."""
+        x, x2 = self._val(B.inputs[0]), self._val(A.inputs[0])
+        if not (x.dense and x2.dense and x.dt == x2.dt and x.phys_c % 64 == 0 and x2.phys_c % 64 == 0
+                and x.phys_c == B.inputs[0].shape[3] and x2.phys_c == A.inputs[0].shape[3]):
+            raise NotImplementedError('two-input conv needs dense inputs with channels in multiples of 64')
+        b = B.attrs
+        n, h, w, cin = x.shape
+        cin2 = x2.shape[3]
+        _, ho, wo, cout = B.shape
+        kh, kw = b['kh'], b['kw']
+        add = A.consumers[0]
+        act, result = None, add
+        self.fused.add(add)
+        relu = self._only_consumer(add, 'relu')
+        if relu is not None:
+            act, result = 'relu', relu
+            self.fused.add(relu)
+        sB, bB = self._fold_bn(b, cout)
+        sA, bA = self._fold_bn(A.attrs, cout)
+        WB = self.weights[b['weights']].astype(np.float64) * sB          # [kh,kw,cin,cout]
+        WA = self.weights[A.attrs['weights']].astype(np.float64) * sA    # [1,1,cin2,cout]
+        k = kh * kw * cin + cin2
+        k_pad, cout_pad = (k + 63) // 64 * 64, (cout + 255) // 256 * 256
+        Wp = np.zeros((cout_pad, k_pad), np.float32)
+        Wp[:cout, :kh * kw * cin] = WB.transpose(3, 0, 1, 2).reshape(cout, -1)
+        Wp[:cout, kh * kw * cin:k] = WA.reshape(cin2, cout).T
+        if x.dt == 'bf16':
+            wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+        else:
+            wdev = torch.from_numpy(Wp).to(self.device)
+        self.keepalive.append(wdev)
+        bdev = self._dev_f32(bA + bB)
+        self.param_bytes += cout * k * _ESZ[x.dt]
+        out = Val(self._alloc(B.shape, x.dt), B.shape, x.dt)
+        for node in (A, B, add, result):
+            self.vals[node] = out
+        d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
+                          dilation=b['rate'], pad_top=b['pad_top'], pad_left=b['pad_left'],
+                          ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE[x.dt],
+                          out_dtype=_CODE[x.dt], y_ld=out.ld, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
+        nbytes = (n * h * w * cin + n * ho * wo * cin2 + cout * k + n * ho * wo * cout) * _ESZ[x.dt]
+        self._emit('conv', b['weights'].rsplit('/', 1)[0] + '+' + A.attrs['weights'].rsplit('/', 2)[-2],
+                   'fss_conv2d_dual_nhwc',
+                   (ctypes.byref(d), x.ptr, x2.ptr, cin2, wdev.data_ptr(), bdev.data_ptr(), None,
+                    out.ptr, self.sh),
+                   flops=2 * n * ho * wo * cout * k, nbytes=nbytes, keep=d)
+
     def _l_conv(self, ln):
         a = ln.attrs
         stem = self._stem_source(ln)
         if stem is not None:
             return self._l_stem_conv(ln, *stem)
+        if ln in self.dual:
+            return self._l_conv_dual(ln, self.dual[ln])
+        partner = self._dual_partner(ln)
+        if partner is not None:
+            self.dual[partner] = ln        # emitted when the 1x1 partner is lowered
+            return
         x = self._val(ln.inputs[0])
         if not x.dense:
             raise NotImplementedError('conv input must be dense')
@@ -786,12 +864,15 @@ class CompiledGraph(object):
                 candidates.append(cfg)
         e0 = e1 = None
         ms = ctypes.c_float()
-        for s in self.steps:
+        for s, fname in zip(self.steps, self.step_fname):
             if s.kind != 'conv':
                 continue
             d = s.keep
             key = ','.join(str(getattr(d, f[0])) for f in d._fields_ if f[0] != 'config')
-            key += ',%d,%d' % (s.args[4] is not None, self.mfma_edge)
+            if fname == 'fss_conv2d_dual_nhwc':
+                key += ',%d,%d,dual%d' % (s.args[6] is not None, self.mfma_edge, s.args[3])
+            else:
+                key += ',%d,%d' % (s.args[4] is not None, self.mfma_edge)
             best = cache.get(key)
             if best is None:
                 if e0 is None:

@@ -114,6 +114,20 @@ int fss_conv_config_info(int config, int info[7]);
 int fss_conv2d_nhwc(const fss_conv_desc* desc, const void* x, const void* w_packed,
                     const float* bias, const void* residual, void* y, void* stream);
 
+/* Sum of two convolutions in one launch:
+ *   y = act(conv(x, W) + conv1x1(x2, W2) + bias [+ residual])
+ * x2: [n,ho,wo,cin2] (the output's spatial size, stride 1).  Packed weights: the K axis
+ * of W (k = (r*kw + s)*cin + c) followed by the cin2 channels of W2, i.e.
+ * k_pad = roundup64(kh*kw*cin + cin2); bias = the sum of both layers' shifts.
+ * Replaces the cascade feature fusion of architectures/icnet_architecture.py:238-252
+ * (conv 1x1 of the high-resolution input + dilated conv 3x3 of the upsampled
+ * low-resolution input, each with batch norm, added, relu) without storing either
+ * addend.  cin and cin2 must be multiples of 64.  x2 = NULL, cin2 = 0 is
+ * fss_conv2d_nhwc. */
+int fss_conv2d_dual_nhwc(const fss_conv_desc* desc, const void* x, const void* x2, int cin2,
+                         const void* w_packed, const float* bias, const void* residual,
+                         void* y, void* stream);
+
 /* Depthwise 3x3-style convolution + bias + activation.
  * Replaces slim.separable_conv2d(num_outputs=None) + batch_norm + relu6
  * (third_party/conv_blocks.py:240-249,280).  w: float [kh*kw][c] (BN folded). */

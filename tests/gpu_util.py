@@ -70,6 +70,37 @@ def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw
     return out[..., :cout]
 
 
+def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, act=None, dt='bf16',
+                config=0):
+    """act(conv(x, w) + conv1x1(x2, w2) + bias) through fss_conv2d_dual_nhwc; host float32
+    arrays in, float32 [n,ho,wo,cout] out."""
+    n, h, wd, cin = x.shape
+    kh, kw, _, cout = w.shape
+    cin2 = x2.shape[3]
+    ho, wo = out_hw
+    k = kh * kw * cin + cin2
+    k_pad, cout_pad = (k + 63) // 64 * 64, (cout + 255) // 256 * 256
+    wp = np.zeros((cout_pad, k_pad), np.float32)
+    wp[:cout, :kh * kw * cin] = w.transpose(3, 0, 1, 2).reshape(cout, -1)
+    wp[:cout, kh * kw * cin:k] = w2.reshape(cin2, cout).T
+    if dt == 'bf16':
+        wdev = torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
+    else:
+        wdev = torch.from_numpy(wp).cuda()
+    xd, x2d = to_dev(x, dt), to_dev(x2, dt)
+    bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda()
+    y = torch.full((n, ho, wo, cout), -77.0, dtype=DT[dt][1], device='cuda')
+    d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride,
+                      dilation=rate, pad_top=pads[0], pad_left=pads[1], ho=ho, wo=wo,
+                      act=_lib.ACT_CODES[act], in_dtype=DT[dt][0], out_dtype=DT[dt][0],
+                      y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad, config=config)
+    torch.cuda.synchronize()
+    _lib.call('fss_conv2d_dual_nhwc', ctypes.byref(d), xd.data_ptr(), x2d.data_ptr(), cin2,
+              wdev.data_ptr(), bd.data_ptr(), None, y.data_ptr(), None)
+    _lib.call('fss_device_sync')
+    return to_host(y)
+
+
 def pack_stem_weights(w, dt):
     """[kh,kw,3,cout] -> device [cout_pad][k_pad], k = tap*4 + channel."""
     kh, kw, cin, cout = w.shape

@@ -130,6 +130,33 @@ def test_conv2d_configs_agree_bitwise(dt):
     assert sorted(by_shape) == [16, 32]
 
 
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_conv2d_dual_is_the_sum_of_two_convolutions(dt):
+    """fss_conv2d_dual_nhwc = relu(conv3x3_dilated(x) + conv1x1(x2) + bias) (the cascade
+    feature fusion) against the oracle's two convolutions added in float64; every tile
+    configuration of a MFMA shape class must give the same bits."""
+    gu, L = _gu(), _lib()
+    rng = np.random.default_rng(21)
+    n, h, wd, cin, cin2, cout = 2, 23, 37, 128, 64, 136
+    x = rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32)
+    x2 = rng.normal(0, 1, (n, h, wd, cin2)).astype(np.float32)
+    w = rng.normal(0, 0.05, (3, 3, cin, cout)).astype(np.float32)
+    w2 = rng.normal(0, 0.1, (1, 1, cin2, cout)).astype(np.float32)
+    bias = rng.normal(0, 1, cout).astype(np.float32)
+    if dt == 'bf16':
+        x, x2, w, w2 = (gu.bf16_round(v) for v in (x, x2, w, w2))
+    ref = O.relu(O.conv2d(x, w, 1, 2, 'SAME', np.float64) + O.conv2d(x2, w2, 1, 1, 'SAME', np.float64) + bias)
+    by_shape = {}
+    for cfg in range(0, L.lib.fss_conv_config_count() + 1):
+        out = gu.conv2d_dual(x, w, x2, w2, bias, 1, 2, (2, 2), (h, wd), 'relu', dt, config=cfg)
+        _close(out, ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'dual conv config %d' % cfg)
+        if cfg:
+            info = (ctypes.c_int * 7)()
+            L.call('fss_conv_config_info', cfg, info)
+            first = by_shape.setdefault(info[6], out)
+            assert np.array_equal(out, first), 'config %d differs inside its shape class' % cfg
+
+
 STEM_CASES = [
     # frame hw, padded hw, sub, k, stride, rate, cout, act, y_ld
     ((37, 70), (41, 75), 1, 3, 2, 1, 32, 'relu', None),      # ICNet 'Conv' (full-resolution branch)
