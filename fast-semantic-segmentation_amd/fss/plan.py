@@ -430,9 +430,10 @@ class CompiledGraph(object):
 
     def _dual_partner(self, ln):
         """The 1x1 convolution A when `relu?(conv ln + A)` can run as one
-        fss_conv2d_dual_nhwc launch (the cascade feature fusion): both without bias and
-        activation, stride 1, the add their only consumer, A later in the order with its
-        input already computable, channel counts multiples of 64."""
+        fss_conv2d_dual_nhwc launch (the cascade feature fusion; a bottleneck's projection
+        shortcut + its last 1x1 conv): both without bias and activation, stride 1, the add
+        their only consumer, A later in the order (the launch is emitted at A's position,
+        where both inputs exist), channel counts multiples of 64."""
         a = ln.attrs
         if not self.fuse_dual or a['biases'] is not None or a['activation'] is not None or a['stride'] != 1:
             return None
@@ -444,7 +445,7 @@ class CompiledGraph(object):
             return None
         b = A.attrs
         if ((b['kh'], b['kw'], b['stride'], b['rate']) != (1, 1, 1, 1) or b['biases'] is not None
-                or b['activation'] is not None or A.shape != ln.shape or A.inputs[0].pos > ln.pos):
+                or b['activation'] is not None or A.shape != ln.shape):
             return None
         if ln.inputs[0].shape[3] % 64 or A.inputs[0].shape[3] % 64:
             return None
