@@ -89,7 +89,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='frames per step per GPU')
+    ap.add_argument('--batch', type=int, default=64, help='frames per step per GPU')
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-latency', action='store_true')
