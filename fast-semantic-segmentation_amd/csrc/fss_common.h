@@ -58,6 +58,14 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, fss_bf16x2));
 }
 
+// 16-byte store that does not keep the line in the caches (outputs far larger than L2 that
+// the same kernel never reads back)
+typedef unsigned fss_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_nt(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  fss_u32x4 v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<fss_u32x4*>(p));
+}
+
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
   static constexpr int kPerChunk = 4;  // elements per 16-byte chunk
@@ -82,6 +90,9 @@ template <> struct Chunk<float> {
   __device__ __forceinline__ void store(float* p) const {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   }
+  __device__ __forceinline__ void store_nt(float* p) const {
+    store16_nt(p, __float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+  }
 };
 template <> struct Chunk<bf16_t> {
   static constexpr int N = 8;
@@ -100,6 +111,10 @@ template <> struct Chunk<bf16_t> {
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  __device__ __forceinline__ void store_nt(bf16_t* p) const {
+    store16_nt(p, pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+               pack_bf16x2(v[6], v[7]));
   }
 };
 

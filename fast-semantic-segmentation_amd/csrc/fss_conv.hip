@@ -477,8 +477,8 @@ conv_igemm_kernel(const ConvArgs a) {
           if constexpr (sizeof(TO) == 4) {
             *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
-            *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                                        pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            store16_nt(dst, pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                       pack_bf16x2(v[6], v[7]));
           }
         } else {
 #pragma unroll

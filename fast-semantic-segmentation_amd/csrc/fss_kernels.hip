@@ -59,7 +59,7 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N
       for (int e = 0; e < E; ++e) best.v[e] = fmaxf(best.v[e], v.v[e]);
     }
   }
-  best.store(y + idx * E);
+  best.store_nt(y + idx * E);
 }
 
 // ----------------------------------------------------------------- subsample
@@ -162,7 +162,7 @@ __global__ void resize_bilinear_kernel(const T* __restrict__ x, T* __restrict__ 
       const float bot = bl.v[e] + (br.v[e] - bl.v[e]) * lx;
       o.v[e] = top + (bot - top) * ly;
     }
-    o.store(out);
+    o.store_nt(out);
   } else {
     const float tl = ElemTraits<T>::load(b + ((size_t)y0 * W + x0) * C);
     const float tr = ElemTraits<T>::load(b + ((size_t)y0 * W + x1) * C);
@@ -241,7 +241,7 @@ __global__ void pyramid_add_kernel(const T* __restrict__ x, T* __restrict__ y, P
     }
 #pragma unroll
     for (int k = 0; k < kPyrPix; ++k)
-      if (ow0 + k < W) acc[k].store(y + row_base + (size_t)k * C + (size_t)ch * E);
+      if (ow0 + k < W) acc[k].store_nt(y + row_base + (size_t)k * C + (size_t)ch * E);
   }
 }
 
@@ -760,7 +760,7 @@ __global__ void dwconv3x3_kernel(const T* __restrict__ x, const float* __restric
     Chunk<T> o;
 #pragma unroll
     for (int e = 0; e < E; ++e) o.v[e] = apply_act(acc[j][e] + b[e], act);
-    o.store(out + (size_t)j * C);
+    o.store_nt(out + (size_t)j * C);
   }
 }
 

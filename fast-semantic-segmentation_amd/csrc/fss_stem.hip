@@ -269,8 +269,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
           if constexpr (NJ % 2 == 0) {
 #pragma unroll
             for (int e = 0; e < NJ / 2; ++e)
-              *reinterpret_cast<uint4*>(dst + 8 * e) =
-                  make_uint4(o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]);
+              store16_nt(dst + 8 * e, o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]);
           } else {
 #pragma unroll
             for (int e = 0; e < NJ; ++e)

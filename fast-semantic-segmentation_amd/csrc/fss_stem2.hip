@@ -478,7 +478,7 @@ stem2_conv_kernel(const Stem2Args a) {
                                __builtin_amdgcn_fmed3f(v[2 * e + 1], lo2, hi2));
           bf16_t* dst = reinterpret_cast<bf16_t*>(a.y) +
                         (((size_t)now.n * a.H2 + oh) * a.W2 + ow) * a.y_ld + 32 * ch + 8 * g;
-          *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+          store16_nt(dst, o[0], o[1], o[2], o[3]);
         }
       }
     };
