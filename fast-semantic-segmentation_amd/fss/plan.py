@@ -847,7 +847,7 @@ class CompiledGraph(object):
             json.dump({'stamp': cls._tune_stamp(), 'entries': dict(sorted((cls._TUNE_CACHE or {}).items()))},
                       f, indent=0)
 
-    def _autotune_convs(self, warm=2, reps=4):
+    def _autotune_convs(self, warm=2, reps=int(os.environ.get('FSS_TUNE_REPS', '4'))):
         """Picks the fastest tile configuration of the conv kernel for each distinct
         layer shape: from the pre-tuned table when the shape is in it, else by timing
         the candidates (HIP events on the plan's stream).  Only configurations of one
