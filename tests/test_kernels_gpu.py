@@ -157,6 +157,66 @@ def test_conv2d_dual_is_the_sum_of_two_convolutions(dt):
             assert np.array_equal(out, first), 'config %d differs inside its shape class' % cfg
 
 
+def test_entry_points_reject_bad_arguments():
+    """Every entry point validates its arguments on the host and returns a non-zero
+    status with a message (no launch, no fault): null pointers, packed-weight dimensions
+    that do not match the descriptor, unsupported channel counts, unaligned pointers."""
+    gu, L = _gu(), _lib()
+    x = torch.zeros((1, 8, 8, 64), dtype=torch.bfloat16, device='cuda')
+    w = torch.zeros((256, 576 + 64), dtype=torch.bfloat16, device='cuda')
+    y = torch.zeros((1, 8, 8, 64), dtype=torch.bfloat16, device='cuda')
+    b = torch.zeros(64, dtype=torch.float32, device='cuda')
+
+    def desc(**kw):
+        d = dict(n=1, h=8, w=8, cin=64, cout=64, kh=3, kw=3, stride=1, dilation=1, pad_top=1, pad_left=1,
+                 ho=8, wo=8, act=0, in_dtype=L.BF16, out_dtype=L.BF16, y_ld=64, res_ld=0, k_pad=576,
+                 cout_pad=256, config=0)
+        d.update(kw)
+        return L.ConvDesc(**d)
+
+    def rejected(name, *args):
+        rc = getattr(L.lib, name)(*args)
+        msg = L.lib.fss_last_error().decode()
+        assert rc != 0 and msg, (name, rc, msg)
+        return msg
+
+    good = desc()
+    assert L.lib.fss_conv2d_nhwc(ctypes.byref(good), x.data_ptr(), w.data_ptr(), b.data_ptr(), None,
+                                 y.data_ptr(), None) == 0
+    assert 'null' in rejected('fss_conv2d_nhwc', ctypes.byref(good), None, w.data_ptr(), b.data_ptr(), None,
+                              y.data_ptr(), None)
+    assert 'mismatch' in rejected('fss_conv2d_nhwc', ctypes.byref(desc(k_pad=512)), x.data_ptr(), w.data_ptr(),
+                                  b.data_ptr(), None, y.data_ptr(), None)
+    assert 'config' in rejected('fss_conv2d_nhwc', ctypes.byref(desc(config=999)), x.data_ptr(), w.data_ptr(),
+                                b.data_ptr(), None, y.data_ptr(), None)
+    assert 'unaligned' in rejected('fss_conv2d_nhwc', ctypes.byref(good), x.data_ptr() + 2, w.data_ptr(),
+                                   b.data_ptr(), None, y.data_ptr(), None)
+    assert 'y_ld' in rejected('fss_conv2d_nhwc', ctypes.byref(desc(y_ld=32)), x.data_ptr(), w.data_ptr(),
+                              b.data_ptr(), None, y.data_ptr(), None)
+    # two-input form: x2 and cin2 go together, channel counts in multiples of 64
+    assert 'together' in rejected('fss_conv2d_dual_nhwc', ctypes.byref(desc(k_pad=640)), x.data_ptr(), None, 64,
+                                  w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None)
+    assert 'multiples of 64' in rejected('fss_conv2d_dual_nhwc', ctypes.byref(desc(k_pad=640)), x.data_ptr(),
+                                         x.data_ptr(), 32, w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None)
+    # fused stem pair: only bfloat16, 32 or 64 channels
+    m3 = (ctypes.c_float * 3)(0, 0, 0)
+    s3 = (ctypes.c_float * 3)(1, 1, 1)
+    frame = torch.zeros((1, 16, 16, 3), dtype=torch.uint8, device='cuda')
+    args = [frame.data_ptr(), w.data_ptr(), b.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 1, 16, 16, 1,
+            16, 16, m3, s3, 64, 1, 1, 8, 8, 0, 64, 1, 1, 4, 4, 0, L.BF16, 64, None]
+    bad = list(args); bad[14] = 48
+    assert 'c1' in rejected('fss_stem2_conv_u8', *bad)
+    bad = list(args); bad[26] = L.F32
+    assert 'bfloat16' in rejected('fss_stem2_conv_u8', *bad)
+    # depthwise / argmax / confusion
+    assert 'null' in rejected('fss_upsample_argmax', None, y.data_ptr(), None, 1, 8, 8, 19, 20, 29, 29, None)
+    assert 'class count' in rejected('fss_upsample_argmax', x.data_ptr(), y.data_ptr(), None, 1, 8, 8, 300, 300,
+                                     29, 29, None)
+    assert 'multiple of 16 bytes' in rejected('fss_dwconv2d_nhwc', x.data_ptr(), b.data_ptr(), b.data_ptr(),
+                                              y.data_ptr(), 1, 8, 8, 12, 3, 3, 1, 1, 1, 1, 8, 8, 0, L.BF16, None)
+    L.call('fss_device_sync')
+
+
 STEM_CASES = [
     # frame hw, padded hw, sub, k, stride, rate, cout, act, y_ld
     ((37, 70), (41, 75), 1, 3, 2, 1, 32, 'relu', None),      # ICNet 'Conv' (full-resolution branch)

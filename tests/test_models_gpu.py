@@ -269,6 +269,37 @@ def test_side_stream_and_stem_fusion_do_not_change_results(dtype):
     assert err <= (1e-5 if dtype == 'float32' else 2e-2), err
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_layer_fusions_agree_with_the_unfused_plan(dtype):
+    """Each cross-layer fusion of the plan compiler (the two stride-2 convolutions of the
+    full-resolution branch in one kernel; the sum of two convolutions as one GEMM) is
+    switched off in turn; logits must agree with the fully fused plan to rounding (the
+    fused forms keep float32 where the unfused ones round an intermediate to the storage
+    type, so bfloat16 differs by at most a few bf16 steps of the logit scale)."""
+    from fss import plan
+    arch, ext, fs, pf, in_shape, pad_shape = CASES[0]
+    g, cfg, outs, weights = build(arch, ext, fs, pf, in_shape, pad_shape)
+    img = np.random.default_rng(5).integers(0, 256, in_shape).astype(np.uint8)
+    ref_plan = plan.CompiledGraph(g, outs, weights, dtype=dtype, streams=1)
+    kinds = [s.kind for s in ref_plan.steps]
+    fnames = list(ref_plan.step_fname)
+    assert 'fss_conv2d_dual_nhwc' in fnames, 'ICNet must use the two-input convolution'
+    if dtype == 'bfloat16':
+        assert 'stem2' in kinds, 'ICNet in bfloat16 must fuse the first two branch convolutions'
+    ref = ref_plan.run(img)[0]
+    scale = float(np.abs(ref).max())
+    for kw in (dict(fuse_stem2=False), dict(fuse_dual=False), dict(fuse_stem2=False, fuse_dual=False)):
+        cg = plan.CompiledGraph(g, outs, weights, dtype=dtype, streams=1, **kw)
+        if not kw.get('fuse_dual', True):
+            assert 'fss_conv2d_dual_nhwc' not in cg.step_fname
+        if not kw.get('fuse_stem2', True):
+            assert not any(s.kind == 'stem2' for s in cg.steps)
+        got = cg.run(img)[0]
+        err = float(np.abs(got - ref).max()) / scale
+        assert err <= (1e-5 if dtype == 'float32' else 2e-2), (kw, err)
+        del cg
+
+
 def test_every_launch_writes_only_its_own_outputs():
     """Runs the launches of an ICNet plan one at a time and checks that no activation
     buffer other than the launch's declared outputs changes (the two-stream schedule
