@@ -15,19 +15,29 @@ CASE = ('icnet', 'dilated_resnet50', 1.0, [1.0, 2.0, 3.0, 4.0])
 PAD = (1025, 2049)
 
 
-def test_full_size_float32_frame_matches_oracle():
+FULL_SIZE = [
+    # model, backbone, filter scale, pooling factors, frame shape, padded size
+    (CASE, (1, 1024, 2048, 3), PAD),                                               # the headline workload
+    (('pspnet', 'dilated_resnet50', 1.0, [1.0, 2.0, 3.0, 6.0]), (1, 713, 713, 3), (713, 713)),
+    (('icnet', 'dilated_mobilenet', 1.0, [1.0, 2.0, 3.0, 4.0]), (1, 1024, 2048, 3), PAD),
+]
+
+
+@pytest.mark.parametrize('case,in_shape,pad', FULL_SIZE, ids=['icnet_resnet50', 'pspnet50_713', 'icnet_mobilenetv2'])
+def test_full_size_float32_frame_matches_oracle(case, in_shape, pad):
+    """One full-size float32 frame of each model family the path serves against the numpy
+    oracle: the stated float32 tolerances (logits 1e-3 of scale, labels >= 99.9 %)."""
     from fss import plan
-    in_shape = (1, 1024, 2048, 3)
-    g, cfg, outs, weights = build(*CASE, in_shape, PAD)
+    g, cfg, outs, weights = build(*case, in_shape, pad)
     img = np.random.default_rng(11).integers(0, 256, in_shape).astype(np.uint8)
-    ref = oracle_logits(*CASE, img, PAD, weights)
+    ref = oracle_logits(*case, img, pad, weights)
     cg = plan.CompiledGraph(g, outs, weights, dtype='float32')
     logits, labels = cg.run(img)
     scale = float(np.abs(ref).max())
     err = float(np.abs(logits - ref).max()) / scale
     agree = float((labels[..., 0] == O.argmax_channels(ref)).mean())
-    print('full size float32: logit err %.3g of scale, argmax agreement %.5f' % (err, agree))
-    assert logits.shape == (1, 1025, 2049, 19)
+    print('full size float32 %s: logit err %.3g of scale, argmax agreement %.5f' % (case[:2], err, agree))
+    assert logits.shape == (1, pad[0], pad[1], 19)
     assert err <= 1e-3            # the stated float32 tolerance
     assert agree >= 0.999
 
