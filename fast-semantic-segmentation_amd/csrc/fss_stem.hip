@@ -55,8 +55,10 @@ template <> struct StemPix<float> {
   }
 };
 
-// NJ = 16-channel groups of output channels (cout_pad = 16 * NJ)
-template <typename T, int NJ>
+// NJ = 16-channel groups of output channels (cout_pad = 16 * NJ); KS = MFMA k steps of the
+// filter when known at compile time (bf16: 7 for 7x7, 2 for 3x3; the tap walk is then
+// unrolled with its patch offsets in registers), 0 = any filter
+template <typename T, int NJ, int KS>
 __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   constexpr int ES = (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -140,9 +142,24 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   // Reads the frame bytes of the patch of tile t: slot k of a lane is patch pixel
   // (wave + 4k, lane).  Branch-free: slots that are not frame pixels read byte 0 of the
   // frame and are replaced at commit, so every load is in flight before any is used.
+  // a tile whose whole patch lies on frame pixels (and not on the last pixel of a frame row,
+  // so that 4-byte loads stay inside the tensor) needs no masks: block-uniform test
+  auto interior = [&](const Tile& t) {
+    const int i0 = t.oh0 * a.stride - a.pad_t, j0 = t.ow0 * a.stride - a.pad_l;
+    return i0 >= 0 && j0 >= 0 && i0 + a.PH <= hreal && j0 + a.PW < wreal;
+  };
   auto fetch = [&](const Tile& t, unsigned (&u)[kStemRows]) {
     const int i0 = t.oh0 * a.stride - a.pad_t, j0 = t.ow0 * a.stride - a.pad_l;
     const uint8_t* frame = a.x + (size_t)t.n * a.Hr * a.Wr * 3;
+    if (interior(t)) {
+      const uint8_t* base = frame + (size_t)i0 * rowstride + (size_t)(j0 + min(lane, a.PW - 1)) * colstride;
+#pragma unroll
+      for (int k = 0; k < kStemRows; ++k) {
+        const int pi = min(wave + 4 * k, a.PH - 1);                  // past the patch: unused
+        u[k] = *reinterpret_cast<const unsigned*>(base + (size_t)pi * rowstride);
+      }
+      return;
+    }
     const unsigned last_word = t.n == a.N - 1 ? (unsigned)(a.Hr * a.Wr * 3 - 4) : 0xffffffffu;
     const int j = j0 + lane;
     const bool col_real = lane < a.PW && (unsigned)j < (unsigned)wreal;
@@ -161,6 +178,22 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   // zero padding of the frame, mean / scale, rounding; stores the patch into LDS
   auto commit = [&](const Tile& t, const unsigned (&u)[kStemRows]) {
     const int i0 = t.oh0 * a.stride - a.pad_t, j0 = t.ow0 * a.stride - a.pad_l;
+    if (interior(t)) {
+#pragma unroll
+      for (int k = 0; k < kStemRows; ++k) {
+        const int pi = wave + 4 * k;
+        if (pi < a.PH) {                                                    // wave-uniform
+          float v[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            v[c] = (float)((u[k] >> (8 * c)) & 255u) - a.mean[c];
+            if (!a.unit_scale) v[c] *= a.scale[c];
+          }
+          if (lane < a.PW) StemPix<T>::store(patch + (size_t)(pi * a.PW + lane) * (4 * ES), v[0], v[1], v[2]);
+        }
+      }
+      return;
+    }
     const int j = j0 + lane;
     const bool col_in = (unsigned)j < (unsigned)a.W, col_real = (unsigned)j < (unsigned)wreal;
 #pragma unroll
@@ -204,7 +237,30 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[mt][nj][q] = 0.f;
 
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 && KS > 0) {
+      // unrolled tap walk: byte offsets of this lane group's two taps per k step
+      int bo[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) bo[mt] = base[mt] * 8;
+#pragma unroll
+      for (int st = 0; st < KS; ++st) {
+        const int2 to = *reinterpret_cast<const int2*>(tapoff + 8 * st + 2 * g);
+        uint4 wa[NJ];
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj)
+          wa[nj] = *reinterpret_cast<const uint4*>(wl + (16 * nj + p) * WROW + (32 * st + 8 * g) * 2);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const uint2 b0 = *reinterpret_cast<const uint2*>(patch + (bo[mt] + to.x * 8));
+          const uint2 b1 = *reinterpret_cast<const uint2*>(patch + (bo[mt] + to.y * 8));
+          const uint4 b = make_uint4(b0.x, b0.y, b1.x, b1.y);
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj)
+            acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8_t, wa[nj]), __builtin_bit_cast(bf16x8_t, b), acc[mt][nj], 0, 0, 0);
+        }
+      }
+    } else if constexpr (sizeof(T) == 2) {
       const int ksteps = a.K4pad / 32;
       for (int st = 0; st < ksteps; ++st) {
         const int2 to = *reinterpret_cast<const int2*>(tapoff + 8 * st + 2 * g);
@@ -285,9 +341,9 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   }
 }
 
-template <typename T, int NJ>
+template <typename T, int NJ, int KS = 0>
 static int launch_stem(const StemArgs& a, size_t smem, hipStream_t stream) {
-  auto kern = stem_conv_kernel<T, NJ>;
+  auto kern = stem_conv_kernel<T, NJ, KS>;
   if (smem > 64 * 1024) {
     static size_t attr_bytes = 0;   // per instantiation
     if (smem > attr_bytes) {
@@ -395,6 +451,10 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
     default: return launch_stem<T, 4>(a, smem, s);               \
   }
   if (dtype == FSS_F32) { FSS_STEM(float) }
+  // the two filters of the reference's networks: unrolled tap walk
+  if (nj == 4 && k_pad == 224) return launch_stem<bf16_t, 4, 7>(a, smem, s);
+  if (nj == 2 && k_pad == 64) return launch_stem<bf16_t, 2, 2>(a, smem, s);
+  if (nj == 4 && k_pad == 64) return launch_stem<bf16_t, 4, 2>(a, smem, s);
   FSS_STEM(bf16_t)
 #undef FSS_STEM
 }
