@@ -616,19 +616,15 @@ __global__ void confusion_kernel(const uint8_t* __restrict__ pred, const uint8_t
   __syncthreads();
   unsigned int* mine = hist + (threadIdx.x >> 6) * cells;
   constexpr int PER = 16;  // consecutive pixels per thread per step
+  const bool vec16 = ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(lab)) & 15) == 0;
   const size_t nthreads = (size_t)gridDim.x * blockDim.x;
   for (size_t base = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * PER; base < count;
        base += nthreads * PER) {
     int run_key = -1;
     unsigned run_len = 0;
-    const size_t end = base + PER < count ? base + PER : count;
-    for (size_t i = base; i < end; ++i) {
-      const int l = lab[i];
+    auto take = [&](int l, int pr) {
       int key = -1;
-      if (l != ignore) {
-        const int pr = pred[i];
-        if (l < nc && pr < nc) key = l * nc + pr;
-      }
+      if (l != ignore && l < nc && pr < nc) key = l * nc + pr;
       if (key == run_key) {
         ++run_len;
       } else {
@@ -636,6 +632,19 @@ __global__ void confusion_kernel(const uint8_t* __restrict__ pred, const uint8_t
         run_key = key;
         run_len = 1;
       }
+    };
+    if (vec16 && base + PER <= count) {
+      // the thread's 16 labels and 16 predictions in one 16-byte load each
+      const uint4 l4 = *reinterpret_cast<const uint4*>(lab + base);
+      const uint4 p4 = *reinterpret_cast<const uint4*>(pred + base);
+      const unsigned lw[4] = {l4.x, l4.y, l4.z, l4.w}, pw[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) take((int)((lw[q] >> (8 * e)) & 255u), (int)((pw[q] >> (8 * e)) & 255u));
+    } else {
+      const size_t end = base + PER < count ? base + PER : count;
+      for (size_t i = base; i < end; ++i) take(lab[i], pred[i]);
     }
     if (run_key >= 0) atomicAdd(&mine[run_key], run_len);
   }
