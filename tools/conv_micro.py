@@ -35,12 +35,14 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--cfg', type=int, default=0)
+    ap.add_argument('--nores', action='store_true', help='drop the residual input')
     args = ap.parse_args()
     from fss import _lib
     import gpu_util as gu
     code, tdt, _ = gu.DT[args.dtype]
     for name in args.names:
         h, w, cin, cout, k, stride, rate, has_res = SHAPES[name]
+        has_res = has_res and not args.nores
         n = args.batch
         keff = k + (k - 1) * (rate - 1)
         ho, wo = -(-h // stride), -(-w // stride)
