@@ -4,6 +4,8 @@
 // of a wave touches chunk i of a pixel row, so a wave reads / writes 1 KiB of
 // consecutive bytes whenever a pixel has >= 64 chunks, and whole pixels
 // otherwise.  Arithmetic is float regardless of the storage dtype.
+#include <algorithm>
+
 #include "fss_common.h"
 
 namespace fss {
@@ -280,11 +282,17 @@ __global__ void copy_channels_kernel(const T* __restrict__ x, int x_ld, T* __res
 // emits, for every level, the sums of its column bins (float).  Stage 2 adds the kh rows
 // of each bin, scales and rounds.  The row sums live in a caller-provided workspace.
 constexpr int kPyrLevels = 4;
+constexpr int kPyrPieces = 32;   // column pieces of a row (<= sum of the levels' bin columns)
+constexpr int kPyrBinCols = 16;  // bin columns of one level
 struct PyrArgs {
   int L, total_cols, total_bins;
   int kh[kPyrLevels], kw[kPyrLevels], bh[kPyrLevels], bw[kPyrLevels];
   int col_off[kPyrLevels], bin_off[kPyrLevels];
   void* y[kPyrLevels];
+  // column pieces: the intervals between consecutive bin edges of all levels; bin column bx
+  // of level l is the pieces plo[l][bx] .. plo[l][bx + 1] - 1
+  int P, edge[kPyrPieces + 1];
+  unsigned char plo[kPyrLevels][kPyrBinCols + 1];
 };
 
 template <typename T>
@@ -330,6 +338,87 @@ __global__ void pyramid_rowsum_kernel(const T* __restrict__ x, float* __restrict
       }
     }
   }
+}
+
+// Same first stage with more parallelism (one thread per row, column PIECE and channel
+// chunk): the row is cut at every bin edge of every level, so each piece belongs to exactly
+// one bin column per level and stage 2 adds whole pieces.  Used when rows x chunks alone do
+// not fill the chip (small batches).
+template <typename T>
+__global__ void pyramid_piecesum_kernel(const T* __restrict__ x, float* __restrict__ part, int N, int H,
+                                        int W, int C, PyrArgs a) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const size_t total = (size_t)N * H * a.P * cc;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ch = (int)(idx % cc);
+  size_t q = idx / cc;
+  const int piece = (int)(q % a.P);
+  const size_t nr = q / a.P;                        // n * H + r
+  const T* row = x + nr * W * C + (size_t)ch * E;
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  for (int col = a.edge[piece]; col < a.edge[piece + 1]; ++col) {
+    Chunk<T> v;
+    v.load(row + (size_t)col * C);
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] += v.v[e];
+  }
+  float* o = part + (nr * a.P + piece) * C + (size_t)ch * E;
+#pragma unroll
+  for (int e = 0; e < E; e += 4)
+    *reinterpret_cast<float4*>(o + e) = make_float4(acc[e], acc[e + 1], acc[e + 2], acc[e + 3]);
+}
+
+// Stage 2 of the small-problem form: kPyrRS adjacent lanes share one (bin, channel chunk),
+// each adds every kPyrRS-th row of the bin, and a butterfly over the lanes finishes the sum
+// (the one-bin level would otherwise walk all rows x pieces in a single thread).
+constexpr int kPyrRS = 8;
+template <typename T>
+__global__ void pyramid_piecebin_kernel(const float* __restrict__ part, int N, int H, int C, PyrArgs a) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const size_t total = (size_t)N * a.total_bins * cc * kPyrRS;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = idx < total;                    // whole groups of kPyrRS lanes are live or not
+  const size_t id = live ? idx : 0;
+  const int rs = (int)(id % kPyrRS);
+  size_t p = id / kPyrRS;
+  const int ch = (int)(p % cc);
+  p /= cc;
+  const int b = (int)(p % a.total_bins);
+  const int n = (int)(p / a.total_bins);
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < kPyrLevels; ++k)
+    if (k < a.L && b >= a.bin_off[k]) l = k;
+  const int lb = b - a.bin_off[l];
+  const int by = lb / a.bw[l], bx = lb - by * a.bw[l];
+  const int p0 = a.plo[l][bx], p1 = a.plo[l][bx + 1];
+  float s[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  for (int r = by * a.kh[l] + rs; r < (by + 1) * a.kh[l]; r += kPyrRS)
+    for (int pc = p0; pc < p1; ++pc) {
+      const float* q = part + (((size_t)n * H + r) * a.P + pc) * C + (size_t)ch * E;
+#pragma unroll
+      for (int e = 0; e < E; e += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(q + e);
+        s[e] += v.x; s[e + 1] += v.y; s[e + 2] += v.z; s[e + 3] += v.w;
+      }
+    }
+#pragma unroll
+  for (int off = 1; off < kPyrRS; off <<= 1)
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] += __shfl_xor(s[e], off);
+  if (!live || rs != 0) return;
+  const float inv = 1.f / (float)(a.kh[l] * a.kw[l]);
+  Chunk<T> o;
+#pragma unroll
+  for (int e = 0; e < E; ++e) o.v[e] = s[e] * inv;
+  o.store(reinterpret_cast<T*>(a.y[l]) + (((size_t)n * a.bh[l] + by) * a.bw[l] + bx) * C + (size_t)ch * E);
 }
 
 template <typename T>
@@ -863,6 +952,10 @@ int fss_avgpool_pyramid_nhwc(const void* x, void* const* y, const int* kh, const
   FSS_REQUIRE(n > 0 && h > 0 && wd > 0, "bad shape");
   PyrArgs a;
   a.L = levels;
+  a.P = 0;
+  for (int i = 0; i <= kPyrPieces; ++i) a.edge[i] = 0;
+  for (int l = 0; l < kPyrLevels; ++l)
+    for (int j = 0; j <= kPyrBinCols; ++j) a.plo[l][j] = 0;
   a.total_cols = a.total_bins = 0;
   for (int l = 0; l < kPyrLevels; ++l) {
     a.kh[l] = a.kw[l] = a.bh[l] = a.bw[l] = 1;
@@ -886,6 +979,41 @@ int fss_avgpool_pyramid_nhwc(const void* x, void* const* y, const int* kh, const
   const int cc = c / (dtype == FSS_F32 ? 4 : 8);
   hipStream_t s = (hipStream_t)stream;
   const size_t t1 = (size_t)n * h * cc, t2 = (size_t)n * a.total_bins * cc;
+  // small problems: cut the rows into pieces at every bin edge for more threads
+  bool pieces_ok = t1 < 98304;
+  for (int l = 0; l < levels; ++l) pieces_ok = pieces_ok && bw[l] <= kPyrBinCols;
+  if (pieces_ok) {
+    int edges[kPyrLevels * kPyrBinCols + 1], ne = 0;
+    edges[ne++] = 0;
+    for (int l = 0; l < levels; ++l)
+      for (int j = 1; j <= bw[l]; ++j) edges[ne++] = j * kw[l];
+    std::sort(edges, edges + ne);
+    ne = (int)(std::unique(edges, edges + ne) - edges);
+    pieces_ok = ne - 1 <= kPyrPieces && ne - 1 <= a.total_cols;
+    if (pieces_ok) {
+      a.P = ne - 1;
+      for (int i = 0; i < ne; ++i) a.edge[i] = edges[i];
+      for (int l = 0; l < levels; ++l)
+        for (int j = 0; j <= bw[l]; ++j)
+          a.plo[l][j] = (unsigned char)(std::lower_bound(edges, edges + ne, j * kw[l]) - edges);
+    }
+  }
+  if (pieces_ok) {
+    const size_t tp = t1 * a.P;
+    if (dtype == FSS_F32) {
+      hipLaunchKernelGGL(pyramid_piecesum_kernel<float>, dim3(grid_for(tp)), dim3(kBlock), 0, s,
+                         (const float*)x, workspace, n, h, wd, c, a);
+      hipLaunchKernelGGL(pyramid_piecebin_kernel<float>, dim3(grid_for(t2 * kPyrRS)), dim3(kBlock), 0, s,
+                         workspace, n, h, c, a);
+    } else {
+      hipLaunchKernelGGL(pyramid_piecesum_kernel<bf16_t>, dim3(grid_for(tp)), dim3(kBlock), 0, s,
+                         (const bf16_t*)x, workspace, n, h, wd, c, a);
+      hipLaunchKernelGGL(pyramid_piecebin_kernel<bf16_t>, dim3(grid_for(t2 * kPyrRS)), dim3(kBlock), 0, s,
+                         workspace, n, h, c, a);
+    }
+    FSS_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == FSS_F32) {
     hipLaunchKernelGGL(pyramid_rowsum_kernel<float>, dim3(grid_for(t1)), dim3(kBlock), 0, s,
                        (const float*)x, workspace, n, h, wd, c, a);

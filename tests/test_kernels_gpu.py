@@ -443,6 +443,36 @@ def test_pools_and_subsample(dt):
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
+def test_avgpool_pyramid_large_batch_path(dt):
+    """fss_avgpool_pyramid_nhwc switches its first stage with the problem size (column pieces
+    for small batches, whole rows for large ones).  The small form is checked against the
+    oracle above; here a batch large enough for the row form must agree with the per-level
+    kernel fss_avgpool_bins_nhwc (itself checked against the oracle)."""
+    gu, L = _gu(), _lib()
+    code, tdt, epc = gu.DT[dt]
+    n, h, wd, c = 40, 33, 65, 2048
+    assert n * h * (c // epc) >= 262144
+    g = torch.Generator(device='cuda').manual_seed(1)
+    xd = torch.randn((n, h, wd, c), device='cuda', generator=g).to(tdt)
+    levels = [(int(h / f), int(wd / f)) for f in (1, 2, 3, 4)]
+    Lv = len(levels)
+    outs = [torch.full((n, h // kh, wd // kw, c), -77.0, dtype=tdt, device='cuda') for kh, kw in levels]
+    ptrs = (ctypes.c_void_p * Lv)(*[o.data_ptr() for o in outs])
+    khs = (ctypes.c_int * Lv)(*[l[0] for l in levels])
+    kws = (ctypes.c_int * Lv)(*[l[1] for l in levels])
+    bhs = (ctypes.c_int * Lv)(*[h // l[0] for l in levels])
+    bws = (ctypes.c_int * Lv)(*[wd // l[1] for l in levels])
+    work = torch.empty((n * h * sum(bws) * c,), dtype=torch.float32, device='cuda')
+    _call('fss_avgpool_pyramid_nhwc', xd.data_ptr(), ptrs, khs, kws, bhs, bws, Lv, work.data_ptr(),
+          work.numel() * 4, n, h, wd, c, code, None)
+    for (kh, kw), o in zip(levels, outs):
+        ref = torch.empty_like(o)
+        _call('fss_avgpool_bins_nhwc', xd.data_ptr(), ref.data_ptr(), n, h, wd, c, kh, kw, h // kh, wd // kw,
+              code, None)
+        _close(gu.to_host(o), gu.to_host(ref), 1e-5 if dt == 'f32' else 1.0 / 128, 'pyramid rows %dx%d' % (kh, kw))
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
 def test_resize_bilinear(dt):
     gu = _gu()
     rng = np.random.default_rng(5)
