@@ -29,6 +29,12 @@
 // pixels of x2 themselves ("one more tap" in the scalar tap walk); used for the cascade
 // feature fusion, where the sum of two convolutions is needed and neither alone.
 //
+// Classifier-head form (HEAD kernels): the activated output tile is not stored; it is
+// multiplied, from the accumulator registers, by a small [classes][cout] matrix and only the
+// class scores leave the block.  The main loop then feeds the MFMA with the operands
+// exchanged (D[cout][pixel]), which puts 4 consecutive output channels of one pixel into each
+// lane: two such D tiles are the 8 k values of that pixel's B operand of the second product.
+//
 // Epilogue: each wave transposes its accumulators through LDS (32 rows at a
 // time) so that bias / residual / activation run on, and the stores write,
 // 16-byte row-contiguous pieces (whole 128-byte lines per row segment), with an
@@ -56,6 +62,10 @@ struct ConvArgs {
   int N, H, W, Cin, Cout, KH, KW, stride, dil, pad_t, pad_l, Ho, Wo, act;
   int Cin2;         // channels of x2: its K segment follows the filter taps in the packed weights
   int M, K, Kpad, y_ld, res_ld, tiles_m, tiles_n;
+  // classifier head (HEAD kernels only): logits = act(conv) * w_head^T + bias_head
+  const void* w_head;       // bf16 [32][Cout], rows >= cout_head zero
+  const float* bias_head;   // [cout_head]
+  int cout_head;
 };
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -130,8 +140,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 // ALIGNED: cin is a multiple of the K tile, so a tile never straddles two filter
 // taps and the tap walk is wave-uniform (scalar) instead of per lane.
+// scores per pixel the classifier-head epilogue can produce (row stride of its staging)
+constexpr int kHeadMax = 20;
+
 template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE,
-          int FM, bool ALIGNED>
+          int FM, bool ALIGNED, bool HEAD = false>
 __global__ void __launch_bounds__(WAVES_M* WAVES_N * 64)
 conv_igemm_kernel(const ConvArgs a) {
   typedef Mma<T, FM> MMA;
@@ -385,10 +398,84 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) MMA::run(acc[i][j], fa[i], fb[j]);
+        for (int j = 0; j < NI; ++j) {
+          if constexpr (HEAD) MMA::run(acc[i][j], fb[j], fa[i]);
+          else MMA::run(acc[i][j], fa[i], fb[j]);
+        }
     }
     slot = slot + 1 == NSTAGE ? 0 : slot + 1;
     fill = fill + 1 == NSTAGE ? 0 : fill + 1;
+  }
+  if constexpr (HEAD) {
+    // acc[i][j] is D[channel][pixel]: lane (lrow, lg) holds channels 16 j + 4 lg + q of pixel
+    // 16 i + lrow of this wave's tile.  Second product, per 32 channels (two D tiles): k
+    // index 8 lg + e of both operands = channel 32 s + 4 lg + (e & 3) + 16 (e >> 2).
+    static_assert(FM == 16 && sizeof(T) == 2 && NI % 2 == 0, "head epilogue: 16x16x32 bf16 tiles");
+    static_assert(WAVES_N * BM * kHeadMax * 4 <= NSTAGE * STAGE_BYTES, "head staging does not fit");
+    wait_vmcnt<0>();
+    __syncthreads();                         // everyone is done with the ring
+    const float act_lo = a.act == FSS_ACT_NONE ? -INFINITY : 0.f;
+    const float act_hi = a.act == FSS_ACT_RELU6 ? 6.f : INFINITY;
+    const T* __restrict__ wh = reinterpret_cast<const T*>(a.w_head);
+    const int n_base = tile_n * BN + wn * WTN;
+    f32x4 acc2[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc2[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NI / 2; ++s) {
+      const int c0 = n_base + 32 * s;
+      if (c0 >= a.Cout) break;               // wave-uniform: Cout is a multiple of 32
+      uint4 wa[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const T* p = wh + (size_t)(ct * 16 + lrow) * a.Cout + c0 + 4 * lg;
+        const uint2 lo = *reinterpret_cast<const uint2*>(p), hi = *reinterpret_cast<const uint2*>(p + 16);
+        wa[ct] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+      if (a.bias != nullptr) {
+        b0 = *reinterpret_cast<const float4*>(a.bias + c0 + 4 * lg);
+        b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 16 + 4 * lg);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const f32x4 d0 = acc[i][2 * s], d1 = acc[i][2 * s + 1];
+        auto cl = [&](float v) { return fminf(fmaxf(v, act_lo), act_hi); };
+        const uint4 fb = make_uint4(pack_bf16x2(cl(d0[0] + b0.x), cl(d0[1] + b0.y)),
+                                    pack_bf16x2(cl(d0[2] + b0.z), cl(d0[3] + b0.w)),
+                                    pack_bf16x2(cl(d1[0] + b1.x), cl(d1[1] + b1.y)),
+                                    pack_bf16x2(cl(d1[2] + b1.z), cl(d1[3] + b1.w)));
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) MMA::run(acc2[i][ct], wa[ct], fb);
+      }
+    }
+    // acc2[i][ct][q] = partial score of class 16 ct + 4 lg + q, pixel 16 i + lrow, over this
+    // wave's channels: one staging plane per channel slice, summed below in a fixed order
+    float* hs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cls = ct * 16 + 4 * lg + q;
+          if (cls < kHeadMax) hs[((wn * BM) + wm * WTM + i * 16 + lrow) * kHeadMax + cls] = acc2[i][ct][q];
+        }
+    __syncthreads();
+    TO* __restrict__ yh = reinterpret_cast<TO*>(a.y);
+    const int nc = a.cout_head;
+    for (int e = tid; e < BM * nc; e += NT) {
+      const int px = e / nc, c = e - px * nc;
+      const int m = tile_m * BM + px;
+      if (m >= a.M) break;                   // px grows with e
+      float v = a.bias_head != nullptr ? a.bias_head[c] : 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_N; ++w) v += hs[(w * BM + px) * kHeadMax + c];
+      ElemTraits<TO>::store(yh + (size_t)m * a.y_ld + c, v);
+    }
+    return;
   }
   // Residual of this lane's output pieces (bf16: 4 values = 8 bytes per piece): loaded
   // here, where the gather registers are dead, so that its latency overlaps the drain
@@ -497,7 +584,7 @@ conv_igemm_kernel(const ConvArgs a) {
 }
 
 template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE,
-          int FM, bool ALIGNED>
+          int FM, bool ALIGNED, bool HEAD = false>
 static int launch_conv_impl(ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BKB;
@@ -508,7 +595,7 @@ static int launch_conv_impl(ConvArgs& a, hipStream_t stream) {
     set_error("fss_conv2d_nhwc: grid out of range");
     return 2;
   }
-  auto kern = conv_igemm_kernel<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, FM, ALIGNED>;
+  auto kern = conv_igemm_kernel<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, FM, ALIGNED, HEAD>;
   if (smem > 64 * 1024) {
     static bool attr_set = false;   // per instantiation
     if (!attr_set) {
@@ -610,6 +697,35 @@ static int dispatch_conv(ConvArgs& a, int config, hipStream_t stream) {
   return 2;
 }
 
+// Classifier-head form: the 16x16x32 configurations whose N tile holds every output channel
+// of the layer (BN >= 128 and cout <= BN); -1 = this configuration cannot.
+template <int BM, int BN, int WM, int WN, int BKB, int NS, int FM>
+static int launch_conv_head(ConvArgs& a, hipStream_t stream) {
+  if constexpr (FM == 16 && BN >= 128) {
+    if (a.Cout > BN) return -1;
+    return launch_conv_impl<bf16_t, float, BM, BN, WM, WN, BKB, NS, FM, true, true>(a, stream);
+  } else {
+    return -1;
+  }
+}
+
+static int dispatch_conv_head(ConvArgs& a, int config, hipStream_t stream) {
+  if (config == 0) config = a.Cout > 128 ? 28 : 29;
+  int rc = -1;
+  switch (config) {
+#define FSS_CASE(ID, BM, BN, WM, WN, BKB, NS, FM) \
+  case ID: rc = launch_conv_head<BM, BN, WM, WN, BKB, NS, FM>(a, stream); break;
+    FSS_CONV_CONFIGS(FSS_CASE)
+#undef FSS_CASE
+    default: break;
+  }
+  if (rc < 0) {
+    set_error("fss_conv2d_dual_head_nhwc: needs a 16x16x32 configuration with an N tile >= cout");
+    return 2;
+  }
+  return rc;
+}
+
 }  // namespace fss
 
 using namespace fss;
@@ -644,9 +760,10 @@ extern "C" int fss_conv_config_info(int config, int info[7]) {
   return 2;
 }
 
-extern "C" int fss_conv2d_dual_nhwc(const fss_conv_desc* d, const void* x, const void* x2, int cin2,
-                                    const void* w_packed, const float* bias, const void* residual,
-                                    void* y, void* stream) {
+// Argument checks and ConvArgs of both two-input entry points.
+static int conv_setup(const fss_conv_desc* d, const void* x, const void* x2, int cin2,
+                      const void* w_packed, const float* bias, const void* residual, void* y,
+                      ConvArgs& a) {
   FSS_REQUIRE(d && x && w_packed && y, "null argument");
   FSS_REQUIRE(d->in_dtype == FSS_F32 || d->in_dtype == FSS_BF16, "bad in_dtype");
   FSS_REQUIRE(d->out_dtype == FSS_F32 || d->out_dtype == FSS_BF16, "bad out_dtype");
@@ -680,7 +797,6 @@ extern "C" int fss_conv2d_dual_nhwc(const fss_conv_desc* d, const void* x, const
               "one input image must be smaller than 2 GiB");
   FSS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0, "unaligned pointer");
 
-  ConvArgs a;
   a.x = x; a.x2 = x2; a.w = w_packed; a.bias = bias; a.res = residual; a.y = y;
   a.N = d->n; a.H = d->h; a.W = d->w; a.Cin = d->cin; a.Cout = d->cout;
   a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.dil = d->dilation;
@@ -690,11 +806,43 @@ extern "C" int fss_conv2d_dual_nhwc(const fss_conv_desc* d, const void* x, const
   a.K = k;
   a.Kpad = k_pad; a.y_ld = d->y_ld; a.res_ld = d->res_ld;
   a.tiles_m = a.tiles_n = 0;
-  hipStream_t s = (hipStream_t)stream;
+  a.w_head = nullptr; a.bias_head = nullptr; a.cout_head = 0;
   FSS_REQUIRE(d->config >= 0 && d->config <= kNumConvConfigs, "config out of range");
+  return 0;
+}
+
+extern "C" int fss_conv2d_dual_nhwc(const fss_conv_desc* d, const void* x, const void* x2, int cin2,
+                                    const void* w_packed, const float* bias, const void* residual,
+                                    void* y, void* stream) {
+  ConvArgs a;
+  if (int rc = conv_setup(d, x, x2, cin2, w_packed, bias, residual, y, a)) return rc;
+  hipStream_t s = (hipStream_t)stream;
   if (d->in_dtype == FSS_F32) return dispatch_conv<float, float>(a, d->config, s);
   if (d->out_dtype == FSS_BF16) return dispatch_conv<bf16_t, bf16_t>(a, d->config, s);
   return dispatch_conv<bf16_t, float>(a, d->config, s);
+}
+
+extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, const void* x2, int cin2,
+                                         const void* w_packed, const float* bias, const void* w_head,
+                                         const float* bias_head, int cout_head, float* y_head,
+                                         int y_head_ld, void* stream) {
+  FSS_REQUIRE(d && w_head && y_head, "null argument");
+  FSS_REQUIRE(d->in_dtype == FSS_BF16, "the classifier-head form takes bf16 activations");
+  FSS_REQUIRE(cout_head > 0 && cout_head <= kHeadMax, "cout_head out of range");
+  FSS_REQUIRE(y_head_ld >= cout_head, "y_head_ld < cout_head");
+  FSS_REQUIRE(d->cout % 32 == 0 && d->cout <= 256, "cout must be a multiple of 32, at most 256");
+  FSS_REQUIRE(((uintptr_t)w_head & 7) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0),
+              "unaligned pointer");
+  ConvArgs a;
+  fss_conv_desc dd = *d;
+  dd.y_ld = d->cout;        // no activation tensor is written; keep the shared checks satisfied
+  if (int rc = conv_setup(&dd, x, x2, cin2, w_packed, bias, nullptr, y_head, a)) return rc;
+  const int bk = 64;        // widest K tile in elements (128-byte tile rows of bf16)
+  FSS_REQUIRE(a.Cin % bk == 0 && a.Cin2 % bk == 0 && a.KH * a.KW <= 62,
+              "the classifier-head form needs cin (and cin2) in multiples of 64");
+  a.y = y_head; a.y_ld = y_head_ld;
+  a.w_head = w_head; a.bias_head = bias_head; a.cout_head = cout_head;
+  return dispatch_conv_head(a, d->config, (hipStream_t)stream);
 }
 
 extern "C" int fss_conv2d_nhwc(const fss_conv_desc* d, const void* x, const void* w_packed,

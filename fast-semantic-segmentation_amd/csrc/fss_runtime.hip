@@ -13,7 +13,7 @@ extern "C" {
 
 const char* fss_last_error(void) { return g_last_error.c_str(); }
 
-int fss_version(void) { return 107; }
+int fss_version(void) { return 108; }
 
 int fss_device_count(int* count) {
   FSS_REQUIRE(count != nullptr, "null argument");

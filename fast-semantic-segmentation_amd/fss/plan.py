@@ -92,6 +92,7 @@ class Step(object):
 # that points into an activation buffer is read)
 _OUT_ARGS = {
     'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,), 'fss_conv2d_dual_nhwc': (7,),
+    'fss_conv2d_dual_head_nhwc': (9,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
     'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1,), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
     'fss_add_act': (2,), 'fss_copy_channels': (2,), 'fss_upsample_argmax': (1, 2),
@@ -108,7 +109,8 @@ class CompiledGraph(object):
 
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
-                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True):
+                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True,
+                 fuse_head=True):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
@@ -133,6 +135,7 @@ class CompiledGraph(object):
         self.fuse_pyramid_pool = fuse_pyramid_pool
         self.fuse_stem2 = fuse_stem2
         self.fuse_dual = fuse_dual
+        self.fuse_head = fuse_head
         self.dual = {}          # 1x1 conv node -> the conv whose output it is added to (one launch)
         self.two_streams = False
         self.release_after = None
@@ -451,6 +454,45 @@ class CompiledGraph(object):
             return None
         return A
 
+    def _head_partner(self, result, cout, dt):
+        """The 1x1 classifier (a convolution with biases, no normalisation or activation, at
+        most 20 classes) that is the only consumer of `result`, when it can run in the
+        epilogue of the convolution producing `result` (fss_conv2d_dual_head_nhwc)."""
+        if not self.fuse_head or dt != 'bf16' or self.mfma_edge != 16 or cout % 32 or cout > 256:
+            return None
+        c = self._only_consumer(result, 'conv2d')
+        if c is None or c in self.dual or self._dual_partner(c) is not None:
+            return None
+        a = c.attrs
+        if ((a['kh'], a['kw'], a['stride'], a['rate']) != (1, 1, 1, 1) or a['biases'] is None
+                or a['activation'] is not None or c.shape[3] > 20 or c.shape[:3] != result.shape[:3]):
+            return None
+        return c
+
+    def _emit_head(self, head, d, x, x2, cin2, wdev, bdev, cout, k, name):
+        """Emits conv (+ second input) + classifier `head` as one launch; the activated
+        cout-channel tensor gets no buffer."""
+        n, ho, wo, ncls = head.shape
+        sc, bh = self._fold_bn(head.attrs, ncls)
+        Wh = np.zeros((32, cout), np.float32)
+        Wh[:ncls] = (self.weights[head.attrs['weights']].astype(np.float64) * sc).reshape(cout, ncls).T
+        whdev = torch.from_numpy(f32_to_bf16_bits(Wh).view(np.int16)).to(self.device)
+        self.keepalive.append(whdev)
+        bhdev = self._dev_f32(bh)
+        self.param_bytes += cout * ncls * 2
+        pc_out = (ncls + 3) // 4 * 4       # as the unfused classifier: float4-readable pixels
+        out = Val(torch.zeros((n, ho, wo, pc_out), dtype=torch.float32, device=self.device),
+                  head.shape, 'f32', phys_c=pc_out)
+        self.vals[head] = out
+        self.fused.add(head)
+        nbytes = ((x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] + n * ho * wo * cin2 + cout * k
+                   + cout * ncls) * 2 + n * ho * wo * ncls * 4)
+        self._emit('conv', name + '+' + head.attrs['weights'].rsplit('/', 2)[-2],
+                   'fss_conv2d_dual_head_nhwc',
+                   (ctypes.byref(d), x.ptr, x2.ptr if x2 is not None else None, cin2, wdev.data_ptr(),
+                    bdev.data_ptr(), whdev.data_ptr(), bhdev.data_ptr(), ncls, out.ptr, out.ld, self.sh),
+                   flops=2 * n * ho * wo * cout * (k + ncls), nbytes=nbytes, keep=d)
+
     def _l_conv_dual(self, A, B):
         """relu?(conv B + conv1x1 A) in one launch; A is the node being lowered."""
         x, x2 = self._val(B.inputs[0]), self._val(A.inputs[0])
@@ -485,6 +527,14 @@ class CompiledGraph(object):
         self.keepalive.append(wdev)
         bdev = self._dev_f32(bA + bB)
         self.param_bytes += cout * k * _ESZ[x.dt]
+        name = b['weights'].rsplit('/', 1)[0] + '+' + A.attrs['weights'].rsplit('/', 2)[-2]
+        head = self._head_partner(result, cout, x.dt)
+        if head is not None:
+            d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
+                              dilation=b['rate'], pad_top=b['pad_top'], pad_left=b['pad_left'],
+                              ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE[x.dt],
+                              out_dtype=_CODE[x.dt], y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
+            return self._emit_head(head, d, x, x2, cin2, wdev, bdev, cout, k, name)
         out = Val(self._alloc(B.shape, x.dt), B.shape, x.dt)
         for node in (A, B, add, result):
             self.vals[node] = out
@@ -493,8 +543,7 @@ class CompiledGraph(object):
                           ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE[x.dt],
                           out_dtype=_CODE[x.dt], y_ld=out.ld, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
         nbytes = (n * h * w * cin + n * ho * wo * cin2 + cout * k + n * ho * wo * cout) * _ESZ[x.dt]
-        self._emit('conv', b['weights'].rsplit('/', 1)[0] + '+' + A.attrs['weights'].rsplit('/', 2)[-2],
-                   'fss_conv2d_dual_nhwc',
+        self._emit('conv', name, 'fss_conv2d_dual_nhwc',
                    (ctypes.byref(d), x.ptr, x2.ptr, cin2, wdev.data_ptr(), bdev.data_ptr(), None,
                     out.ptr, self.sh),
                    flops=2 * n * ho * wo * cout * k, nbytes=nbytes, keep=d)
@@ -548,6 +597,16 @@ class CompiledGraph(object):
         self.keepalive.append(wdev)
         bdev = self._dev_f32(bias)
         self.param_bytes += cout * kh * kw * cin * _ESZ[in_dt]
+        head = None
+        if res is None and a['biases'] is None and pc == cin and cin % 64 == 0 and a['stride'] == 1:
+            head = self._head_partner(result, cout, in_dt)
+        if head is not None:
+            d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc, cout=cout, kh=kh, kw=kw, stride=1,
+                              dilation=a['rate'], pad_top=a['pad_top'], pad_left=a['pad_left'],
+                              ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE[in_dt],
+                              out_dtype=_CODE[in_dt], y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
+            return self._emit_head(head, d, x, None, 0, wdev, bdev, cout, kh * kw * cin,
+                                   a['weights'].rsplit('/', 1)[0])
         if a['biases'] is not None:
             # logits: pixel stride rounded up to 16 bytes so later kernels read float4s;
             # the pad channel is zero and never looked at
@@ -858,11 +917,12 @@ class CompiledGraph(object):
         cache = CompiledGraph._TUNE_CACHE
         ncfg = lib.fss_conv_config_count()
         info = (ctypes.c_int * 7)()
-        candidates = []
+        candidates, tile_n = [], {}
         for cfg in range(1, ncfg + 1):
             _lib.call('fss_conv_config_info', cfg, info)
             if info[6] == self.mfma_edge:
                 candidates.append(cfg)
+                tile_n[cfg] = info[1]
         e0 = e1 = None
         ms = ctypes.c_float()
         for s, fname in zip(self.steps, self.step_fname):
@@ -870,8 +930,13 @@ class CompiledGraph(object):
                 continue
             d = s.keep
             key = ','.join(str(getattr(d, f[0])) for f in d._fields_ if f[0] != 'config')
+            cands = candidates
             if fname == 'fss_conv2d_dual_nhwc':
                 key += ',%d,%d,dual%d' % (s.args[6] is not None, self.mfma_edge, s.args[3])
+            elif fname == 'fss_conv2d_dual_head_nhwc':
+                # the N tile must hold every output channel (16x16 MFMA shape only)
+                key += ',head%d,%d,dual%d' % (s.args[8], self.mfma_edge, s.args[3])
+                cands = [c for c in candidates if tile_n[c] >= max(d.cout, 128)]
             else:
                 key += ',%d,%d' % (s.args[4] is not None, self.mfma_edge)
             best = cache.get(key)
@@ -881,7 +946,7 @@ class CompiledGraph(object):
                     _lib.call('fss_event_create', ctypes.byref(e0))
                     _lib.call('fss_event_create', ctypes.byref(e1))
                 best, best_ms = 0, float('inf')
-                for cfg in candidates:
+                for cfg in cands:
                     d.config = cfg
                     for _ in range(warm):
                         check(s.fn(*s.args), s.name)

@@ -128,6 +128,22 @@ int fss_conv2d_dual_nhwc(const fss_conv_desc* desc, const void* x, const void* x
                          const void* w_packed, const float* bias, const void* residual,
                          void* y, void* stream);
 
+/* Convolution (one or two inputs, as above) followed by a 1x1 classifier, in one launch:
+ *   y_head[m][c] = bias_head[c] + sum_n bf16(act(conv(x, W) + conv1x1(x2, W2) + bias))[m][n] * w_head[c][n]
+ * The activated cout-channel tensor is never stored; only the cout_head class scores per
+ * pixel leave the kernel (float32, pixel stride y_head_ld).  Replaces the last cascade
+ * feature fusion + the `Predictions` slim.conv2d of architectures/icnet_architecture.py:
+ * 131-142,238-252 (the classifier applied before the x2 upsampling, which commutes with a
+ * 1x1 convolution).  bf16 activations only; cin (and cin2) multiples of 64; cout a multiple
+ * of 32 and <= 256; cout_head <= 20; w_head: bf16 [32][cout], rows >= cout_head zero;
+ * desc->config: 0 or a 16x16-MFMA configuration whose block columns >= cout;
+ * desc->out_dtype, y_ld, res_ld are ignored.  Equals fss_conv2d_dual_nhwc followed by
+ * fss_conv2d_nhwc up to float summation order. */
+int fss_conv2d_dual_head_nhwc(const fss_conv_desc* desc, const void* x, const void* x2, int cin2,
+                              const void* w_packed, const float* bias, const void* w_head,
+                              const float* bias_head, int cout_head, float* y_head,
+                              int y_head_ld, void* stream);
+
 /* Depthwise 3x3-style convolution + bias + activation.
  * Replaces slim.separable_conv2d(num_outputs=None) + batch_norm + relu6
  * (third_party/conv_blocks.py:240-249,280).  w: float [kh*kw][c] (BN folded). */

@@ -101,6 +101,47 @@ def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, 
     return to_host(y)
 
 
+def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), out_hw=None, act='relu',
+                     config=0, y_ld=None):
+    """bf16(act(conv(x, w) + conv1x1(x2, w2) + bias)) times the [cout, classes] matrix w_head
+    + b_head through fss_conv2d_dual_head_nhwc (bfloat16 activations); x2 / w2 may be None.
+    Returns float32 [n,ho,wo,classes]."""
+    n, h, wd, cin = x.shape
+    kh, kw, _, cout = w.shape
+    cin2 = x2.shape[3] if x2 is not None else 0
+    ncls = w_head.shape[1]
+    ho, wo = out_hw
+    k = kh * kw * cin + cin2
+    k_pad, cout_pad = (k + 63) // 64 * 64, (cout + 255) // 256 * 256
+    wp = np.zeros((cout_pad, k_pad), np.float32)
+    wp[:cout, :kh * kw * cin] = w.transpose(3, 0, 1, 2).reshape(cout, -1)
+    if cin2:
+        wp[:cout, kh * kw * cin:k] = w2.reshape(cin2, cout).T
+    wdev = torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
+    wh = np.zeros((32, cout), np.float32)
+    wh[:ncls] = w_head.T
+    whdev = torch.from_numpy(f32_to_bf16_bits(wh).view(np.int16)).cuda()
+    xd = to_dev(x, 'bf16')
+    x2d = to_dev(x2, 'bf16') if cin2 else None
+    bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda()
+    bh = torch.from_numpy(np.asarray(b_head, np.float32)).cuda()
+    ld = y_ld or ncls
+    y = torch.full((n, ho, wo, ld), -77.0, dtype=torch.float32, device='cuda')
+    d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
+                      dilation=rate, pad_top=pads[0], pad_left=pads[1], ho=ho, wo=wo,
+                      act=_lib.ACT_CODES[act], in_dtype=_lib.BF16, out_dtype=_lib.BF16,
+                      y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad, config=config)
+    torch.cuda.synchronize()
+    _lib.call('fss_conv2d_dual_head_nhwc', ctypes.byref(d), xd.data_ptr(),
+              x2d.data_ptr() if cin2 else None, cin2, wdev.data_ptr(), bd.data_ptr(),
+              whdev.data_ptr(), bh.data_ptr(), ncls, y.data_ptr(), ld, None)
+    _lib.call('fss_device_sync')
+    out = to_host(y)
+    if ld != ncls:
+        assert np.all(out[..., ncls:] == -77.0), 'kernel wrote outside its channel slice'
+    return out[..., :ncls]
+
+
 def pack_stem_weights(w, dt):
     """[kh,kw,3,cout] -> device [cout_pad][k_pad], k = tap*4 + channel."""
     kh, kw, cin, cout = w.shape

@@ -157,6 +157,48 @@ def test_conv2d_dual_is_the_sum_of_two_convolutions(dt):
             assert np.array_equal(out, first), 'config %d differs inside its shape class' % cfg
 
 
+@pytest.mark.parametrize('cout,cin2', [(256, 64), (128, 0), (96, 128)])
+def test_conv2d_head_is_conv_then_classifier(cout, cin2):
+    """fss_conv2d_dual_head_nhwc = the two-input convolution, rounded to bfloat16 as the
+    unfused plan stores it, followed by the 1x1 classifier, against the oracle in float64;
+    every configuration that can hold the layer must agree to float summation order, the
+    others must refuse."""
+    gu, L = _gu(), _lib()
+    rng = np.random.default_rng(22)
+    n, h, wd, cin, ncls = 2, 19, 31, 64, 19
+    x = gu.bf16_round(rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32))
+    w = gu.bf16_round(rng.normal(0, 0.05, (3, 3, cin, cout)).astype(np.float32))
+    x2 = w2 = None
+    conv = O.conv2d(x, w, 1, 2, 'SAME', np.float64)
+    if cin2:
+        x2 = gu.bf16_round(rng.normal(0, 1, (n, h, wd, cin2)).astype(np.float32))
+        w2 = gu.bf16_round(rng.normal(0, 0.1, (1, 1, cin2, cout)).astype(np.float32))
+        conv = conv + O.conv2d(x2, w2, 1, 1, 'SAME', np.float64)
+    bias = rng.normal(0, 1, cout).astype(np.float32)
+    w_head = gu.bf16_round(rng.normal(0, 0.1, (cout, ncls)).astype(np.float32))
+    b_head = rng.normal(0, 1, ncls).astype(np.float32)
+    act = gu.bf16_round(O.relu(conv + bias).astype(np.float32)).astype(np.float64)
+    ref = act.reshape(-1, cout) @ w_head.astype(np.float64) + b_head
+    ref = ref.reshape(n, h, wd, ncls)
+    ran = 0
+    for cfg in range(0, L.lib.fss_conv_config_count() + 1):
+        info = (ctypes.c_int * 7)()
+        if cfg:
+            L.call('fss_conv_config_info', cfg, info)
+        if cfg and not (info[6] == 16 and info[1] >= max(cout, 128)):
+            with pytest.raises(RuntimeError, match='16x16x32'):
+                gu.conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, 2, (2, 2), (h, wd), config=cfg)
+            continue
+        out = gu.conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, 2, (2, 2), (h, wd), config=cfg,
+                                  y_ld=20 if cfg % 2 else None)
+        # a bfloat16 rounding of an activation that sits on a tie may go the other way
+        # (the conv sum is formed in another order than the oracle's): 2^-8 * |w_head| * act
+        _close(out, ref, 2e-2, 'head conv config %d' % cfg)
+        assert np.mean(np.abs(out - ref) > 2e-3) < 0.01, 'config %d' % cfg
+        ran += 1
+    assert ran >= 3
+
+
 def test_entry_points_reject_bad_arguments():
     """Every entry point validates its arguments on the host and returns a non-zero
     status with a message (no launch, no fault): null pointers, packed-weight dimensions

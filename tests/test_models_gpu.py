@@ -272,7 +272,8 @@ def test_side_stream_and_stem_fusion_do_not_change_results(dtype):
 @pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
 def test_layer_fusions_agree_with_the_unfused_plan(dtype):
     """Each cross-layer fusion of the plan compiler (the two stride-2 convolutions of the
-    full-resolution branch in one kernel; the sum of two convolutions as one GEMM) is
+    full-resolution branch in one kernel; the sum of two convolutions as one GEMM; the
+    classifier in the epilogue of the last convolution) is
     switched off in turn; logits must agree with the fully fused plan to rounding (the
     fused forms keep float32 where the unfused ones round an intermediate to the storage
     type, so bfloat16 differs by at most a few bf16 steps of the logit scale)."""
@@ -286,10 +287,14 @@ def test_layer_fusions_agree_with_the_unfused_plan(dtype):
     assert 'fss_conv2d_dual_nhwc' in fnames, 'ICNet must use the two-input convolution'
     if dtype == 'bfloat16':
         assert 'stem2' in kinds, 'ICNet in bfloat16 must fuse the first two branch convolutions'
+        assert 'fss_conv2d_dual_head_nhwc' in fnames, 'ICNet in bfloat16 must fuse the classifier'
     ref = ref_plan.run(img)[0]
     scale = float(np.abs(ref).max())
-    for kw in (dict(fuse_stem2=False), dict(fuse_dual=False), dict(fuse_stem2=False, fuse_dual=False)):
+    for kw in (dict(fuse_stem2=False), dict(fuse_dual=False), dict(fuse_head=False),
+               dict(fuse_stem2=False, fuse_dual=False, fuse_head=False)):
         cg = plan.CompiledGraph(g, outs, weights, dtype=dtype, streams=1, **kw)
+        if not kw.get('fuse_head', True):
+            assert 'fss_conv2d_dual_head_nhwc' not in cg.step_fname
         if not kw.get('fuse_dual', True):
             assert 'fss_conv2d_dual_nhwc' not in cg.step_fname
         if not kw.get('fuse_stem2', True):
