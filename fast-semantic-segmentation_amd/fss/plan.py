@@ -110,7 +110,7 @@ class CompiledGraph(object):
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
                  fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True,
-                 fuse_head=True):
+                 fuse_head=True, collapse_zooms=True):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
@@ -136,6 +136,7 @@ class CompiledGraph(object):
         self.fuse_stem2 = fuse_stem2
         self.fuse_dual = fuse_dual
         self.fuse_head = fuse_head
+        self.collapse_zooms = collapse_zooms
         self.dual = {}          # 1x1 conv node -> the conv whose output it is added to (one launch)
         self.two_streams = False
         self.release_after = None
@@ -823,6 +824,19 @@ class CompiledGraph(object):
         d = self.lazy.get(src)
         full_ptr = None
         n, ho, wo, _ = ln.shape
+        if d and d[0] == 'resize' and d[2]:
+            # Two align_corners zooms in a row, the first by a whole factor (its output keeps
+            # every source pixel as a knot): inside one source cell the first zoom samples a
+            # bilinear function, which the second reproduces exactly from those samples, so
+            # the pair equals one zoom from the source (to float rounding).
+            inner = d[1]
+            d0 = self.lazy.get(inner)
+            if (self.collapse_zooms and d0 and d0[0] == 'resize' and d0[2] and not inner.is_output
+                    and len(inner.consumers) == 1 and not src.is_output and len(src.consumers) == 1):
+                (h0, w0), (h1, w1) = d0[1].shape[1:3], inner.shape[1:3]
+                if h0 > 1 and w0 > 1 and (h1 - 1) % (h0 - 1) == 0 and (w1 - 1) % (w0 - 1) == 0:
+                    self.lazy.pop(inner)
+                    d = (d[0], d0[1]) + tuple(d[2:])
         if d and d[0] == 'resize' and d[2] and self._val(d[1]).dt == 'f32':
             x = self._val(d[1])
             if src.is_output or len(src.consumers) > 1:

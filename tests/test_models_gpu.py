@@ -114,6 +114,38 @@ def test_classifier_commute_is_exact_enough():
     assert np.abs(a - b).max() <= 1e-4 * np.abs(b).max()
 
 
+def test_two_zooms_before_the_argmax_run_as_one():
+    """The evaluator's label map is argmax(zoom x4(zoom x2(classifier scores))), both zooms
+    align_corners: the plan interpolates once, x8, from the scores (inside one source cell the
+    first zoom samples a bilinear function, which the second reproduces).  Labels must agree
+    with the two-step plan and with the oracle's two-step float32 computation to the stated
+    argmax tolerance; only near-ties may differ."""
+    from google.protobuf import text_format
+    from protos import pipeline_pb2
+    from builders import model_builder
+    from fss import graph as G, synth, plan
+    from libs import evaluator
+    arch, ext, fs, pf, in_shape, pad_shape = CASES[0]
+    cfg = pipeline_pb2.PipelineConfig()
+    text_format.Merge(CFG % dict(arch=arch, ext=ext, fs=fs, pf=pf, h=pad_shape[0], w=pad_shape[1]), cfg)
+    g = G.reset_default_graph()
+    _, model = model_builder.build(cfg.model, is_training=False)
+    preds, ph = evaluator.create_predictions_and_labels(model, in_shape[1:], pad_shape[0], pad_shape[1],
+                                                        False, in_shape[0])
+    weights = synth.make_weights(g.variables, seed=1234, input_std=70.0)
+    img = np.random.default_rng(8).integers(0, 256, in_shape).astype(np.uint8)
+    one = plan.CompiledGraph(g, [preds], weights, dtype='float32')
+    two = plan.CompiledGraph(g, [preds], weights, dtype='float32', collapse_zooms=False)
+    n_resize = lambda cg: sum(1 for s in cg.steps if s.kind == 'resize')
+    assert n_resize(one) == n_resize(two) - 1
+    la, lb = one.run(img)[0][..., 0], two.run(img)[0][..., 0]
+    assert la.shape == (in_shape[0],) + tuple(pad_shape)
+    assert float((la == lb).mean()) >= 0.9999
+    ref = oracle_logits(arch, ext, fs, pf, img, pad_shape, weights)      # after the x2 zoom
+    ref = O.resize_bilinear(ref, pad_shape[0], pad_shape[1], True)
+    assert float((la == O.argmax_channels(ref)).mean()) >= 0.999
+
+
 def test_inference_session_matches_oracle():
     """libs.exporter surface: uint8 HWC image in, float32 [1,h,w,3] colours out."""
     from libs import exporter
