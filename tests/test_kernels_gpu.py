@@ -240,6 +240,20 @@ def test_entry_points_reject_bad_arguments():
                                   w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None)
     assert 'multiples of 64' in rejected('fss_conv2d_dual_nhwc', ctypes.byref(desc(k_pad=640)), x.data_ptr(),
                                          x.data_ptr(), 32, w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None)
+    # classifier-head form: bfloat16, at most 20 classes, a 16x16-MFMA configuration
+    yh = torch.zeros((1, 8, 8, 20), dtype=torch.float32, device='cuda')
+    head = [x.data_ptr(), None, 0, w.data_ptr(), b.data_ptr(), w.data_ptr(), b.data_ptr(), 19, yh.data_ptr(),
+            20, None]
+    assert L.lib.fss_conv2d_dual_head_nhwc(ctypes.byref(good), *head) == 0
+    bad = list(head); bad[7] = 21
+    assert 'cout_head' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
+    bad = list(head); bad[9] = 16
+    assert 'y_head_ld' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
+    bad = list(head); bad[5] = None
+    assert 'null' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
+    assert 'bf16' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(desc(in_dtype=L.F32, out_dtype=L.F32)),
+                              *head)
+    assert '16x16x32' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(desc(config=1)), *head)
     # fused stem pair: only bfloat16, 32 or 64 channels
     m3 = (ctypes.c_float * 3)(0, 0, 0)
     s3 = (ctypes.c_float * 3)(1, 1, 1)
