@@ -441,7 +441,18 @@ conv_igemm_kernel(const ConvArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const f32x4 d0 = acc[i][2 * s], d1 = acc[i][2 * s + 1];
+        f32x4 d0 = acc[i][2 * s], d1 = acc[i][2 * s + 1];
+        if (a.res != nullptr) {
+          const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
+          if (m < a.M) {
+            const T* rp = reinterpret_cast<const T*>(a.res) + (size_t)m * a.res_ld + c0 + 4 * lg;
+            const uint2 r0 = *reinterpret_cast<const uint2*>(rp), r1 = *reinterpret_cast<const uint2*>(rp + 16);
+            d0[0] += __uint_as_float(r0.x << 16); d0[1] += __uint_as_float(r0.x & 0xffff0000u);
+            d0[2] += __uint_as_float(r0.y << 16); d0[3] += __uint_as_float(r0.y & 0xffff0000u);
+            d1[0] += __uint_as_float(r1.x << 16); d1[1] += __uint_as_float(r1.x & 0xffff0000u);
+            d1[2] += __uint_as_float(r1.y << 16); d1[3] += __uint_as_float(r1.y & 0xffff0000u);
+          }
+        }
         auto cl = [&](float v) { return fminf(fmaxf(v, act_lo), act_hi); };
         const uint4 fb = make_uint4(pack_bf16x2(cl(d0[0] + b0.x), cl(d0[1] + b0.y)),
                                     pack_bf16x2(cl(d0[2] + b0.z), cl(d0[3] + b0.w)),
@@ -823,9 +834,9 @@ extern "C" int fss_conv2d_dual_nhwc(const fss_conv_desc* d, const void* x, const
 }
 
 extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, const void* x2, int cin2,
-                                         const void* w_packed, const float* bias, const void* w_head,
-                                         const float* bias_head, int cout_head, float* y_head,
-                                         int y_head_ld, void* stream) {
+                                         const void* w_packed, const float* bias, const void* residual,
+                                         const void* w_head, const float* bias_head, int cout_head,
+                                         float* y_head, int y_head_ld, void* stream) {
   FSS_REQUIRE(d && w_head && y_head, "null argument");
   FSS_REQUIRE(d->in_dtype == FSS_BF16, "the classifier-head form takes bf16 activations");
   FSS_REQUIRE(cout_head > 0 && cout_head <= kHeadMax, "cout_head out of range");
@@ -836,7 +847,9 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
   ConvArgs a;
   fss_conv_desc dd = *d;
   dd.y_ld = d->cout;        // no activation tensor is written; keep the shared checks satisfied
-  if (int rc = conv_setup(&dd, x, x2, cin2, w_packed, bias, nullptr, y_head, a)) return rc;
+  FSS_REQUIRE(residual == nullptr || (((uintptr_t)residual & 7) == 0 && d->res_ld % 4 == 0),
+              "unaligned residual");
+  if (int rc = conv_setup(&dd, x, x2, cin2, w_packed, bias, residual, y_head, a)) return rc;
   const int bk = 64;        // widest K tile in elements (128-byte tile rows of bf16)
   FSS_REQUIRE(a.Cin % bk == 0 && a.Cin2 % bk == 0 && a.KH * a.KW <= 62,
               "the classifier-head form needs cin (and cin2) in multiples of 64");

@@ -262,6 +262,114 @@ __global__ void add_act_kernel(const T* __restrict__ a, const T* __restrict__ b,
   va.store(y + idx * E);
 }
 
+// ------------------------------------- x2 zoom behind a convolution (border pieces)
+// conv3x3 with dilation 2 of an align_corners x2 zoom equals the x2 zoom of the plain conv3x3
+// of the source, except on output rows / columns 1 and 2H-3 / 2W-3: there one of the two
+// (four) source results that are averaged must not see the border row (column) of the source,
+// because the tap that reaches it lands on the zero padding of the zoomed map.  These results
+// come from convolutions of small crops of the source in which that row / column is zero:
+//   tb: [2n][3][W][C]  top (rows 0,1,2; row 0 zero) and bottom (rows H-3..H-1; last zero)
+//   lr: [2n][H][3][C]  left (columns 0,1,2; column 0 zero) and right
+//   cn: [4n][3][3][C]  corners TL, TR, BL, BR with both the border row and column zero
+template <typename T>
+__global__ void zoom2_border_gather_kernel(const T* __restrict__ x, T* __restrict__ tb, T* __restrict__ lr,
+                                           T* __restrict__ cn, int N, int H, int W, int C) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const size_t n_tb = (size_t)2 * N * 3 * W * cc, n_lr = (size_t)2 * N * H * 3 * cc, n_cn = (size_t)4 * N * 9 * cc;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_tb + n_lr + n_cn) return;
+  T* dst;
+  int f, sy, sx;          // frame, source row, source column
+  bool zero;
+  int ch;
+  if (idx < n_tb) {
+    dst = tb + idx * E;
+    ch = (int)(idx % cc); idx /= cc;
+    const int xw = (int)(idx % W); idx /= W;
+    const int r = (int)(idx % 3); idx /= 3;
+    const int side = (int)(idx / N);
+    f = (int)(idx % N);
+    sy = side == 0 ? r : H - 3 + r;
+    sx = xw;
+    zero = side == 0 ? r == 0 : r == 2;
+  } else if (idx < n_tb + n_lr) {
+    idx -= n_tb;
+    dst = lr + idx * E;
+    ch = (int)(idx % cc); idx /= cc;
+    const int c3 = (int)(idx % 3); idx /= 3;
+    const int yh = (int)(idx % H); idx /= H;
+    const int side = (int)(idx / N);
+    f = (int)(idx % N);
+    sy = yh;
+    sx = side == 0 ? c3 : W - 3 + c3;
+    zero = side == 0 ? c3 == 0 : c3 == 2;
+  } else {
+    idx -= n_tb + n_lr;
+    dst = cn + idx * E;
+    ch = (int)(idx % cc); idx /= cc;
+    const int c3 = (int)(idx % 3); idx /= 3;
+    const int r = (int)(idx % 3); idx /= 3;
+    const int k = (int)(idx / N);      // 0 TL, 1 TR, 2 BL, 3 BR
+    f = (int)(idx % N);
+    const bool bottom = k >= 2, right = (k & 1) != 0;
+    sy = bottom ? H - 3 + r : r;
+    sx = right ? W - 3 + c3 : c3;
+    zero = (bottom ? r == 2 : r == 0) || (right ? c3 == 2 : c3 == 0);
+  }
+  Chunk<T> v;
+  if (zero) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v.v[e] = 0.f;
+  } else {
+    v.load(x + (((size_t)f * H + sy) * W + sx) * C + (size_t)ch * E);
+  }
+  v.store(dst);
+}
+
+// r[2H-1][2W-1] = the x2 zoom of y[H][W] with the border results substituted as described
+// above (ytb / ylr / ycn = the convolutions of tb / lr / cn; their middle row / column /
+// pixel is used).
+template <typename T>
+__global__ void zoom2_conv_commute_kernel(const T* __restrict__ y, const T* __restrict__ ytb,
+                                          const T* __restrict__ ylr, const T* __restrict__ ycn,
+                                          T* __restrict__ r, int N, int H, int W, int C) {
+  constexpr int E = Chunk<T>::N;
+  const int cc = C / E;
+  const int Ho = 2 * H - 1, Wo = 2 * W - 1;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)N * Ho * Wo * cc) return;
+  T* dst = r + idx * E;
+  const int ch = (int)(idx % cc); idx /= cc;
+  const int q = (int)(idx % Wo); idx /= Wo;
+  const int p = (int)(idx % Ho);
+  const int f = (int)(idx / Ho);
+  const int i0 = p >> 1, j0 = q >> 1, ni = 1 + (p & 1), nj = 1 + (q & 1);
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  for (int a = 0; a < ni; ++a)
+    for (int b = 0; b < nj; ++b) {
+      const int i = i0 + a, j = j0 + b;
+      const int rf = (p == 1 && i == 1) ? 1 : (p == Ho - 2 && i == H - 2) ? 2 : 0;   // 1 top, 2 bottom
+      const int cf = (q == 1 && j == 1) ? 1 : (q == Wo - 2 && j == W - 2) ? 2 : 0;   // 1 left, 2 right
+      const T* src;
+      if (rf == 0 && cf == 0) src = y + (((size_t)f * H + i) * W + j) * C;
+      else if (cf == 0) src = ytb + ((((size_t)(rf - 1) * N + f) * 3 + 1) * W + j) * C;
+      else if (rf == 0) src = ylr + ((((size_t)(cf - 1) * N + f) * H + i) * 3 + 1) * C;
+      else src = ycn + (((size_t)((rf - 1) * 2 + (cf - 1)) * N + f) * 9 + 4) * C;
+      Chunk<T> v;
+      v.load(src + (size_t)ch * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] += v.v[e];
+    }
+  const float sc = 1.0f / (float)(ni * nj);
+  Chunk<T> o;
+#pragma unroll
+  for (int e = 0; e < E; ++e) o.v[e] = acc[e] * sc;
+  o.store_nt(dst);
+}
+
 // ------------------------------------------------------------- channel copy
 template <typename T>
 __global__ void copy_channels_kernel(const T* __restrict__ x, int x_ld, T* __restrict__ y, int y_ld,
@@ -1141,6 +1249,48 @@ int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho, i
   else
     hipLaunchKernelGGL(preprocess_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, x,
                        (bf16_t*)y, n, h, wd, ho, wo, c_out, a);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_zoom2_border_gather(const void* x, void* tb, void* lr, void* cn, int n, int h, int wd, int c,
+                            int dtype, void* stream) {
+  FSS_REQUIRE(x && tb && lr && cn, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_CHUNK_OK(c, dtype);
+  FSS_ALIGNED(x); FSS_ALIGNED(tb); FSS_ALIGNED(lr); FSS_ALIGNED(cn);
+  FSS_REQUIRE(n > 0 && h >= 4 && wd >= 4, "bad shape (h, w >= 4)");
+  const int cc = c / (dtype == FSS_F32 ? 4 : 8);
+  const size_t total = ((size_t)2 * n * 3 * wd + (size_t)2 * n * h * 3 + (size_t)4 * n * 9) * cc;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL(zoom2_border_gather_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const float*)x, (float*)tb, (float*)lr, (float*)cn, n, h, wd, c);
+  else
+    hipLaunchKernelGGL(zoom2_border_gather_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const bf16_t*)x, (bf16_t*)tb, (bf16_t*)lr, (bf16_t*)cn, n, h, wd, c);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_zoom2_conv_commute(const void* y, const void* ytb, const void* ylr, const void* ycn, void* r,
+                           int n, int h, int wd, int c, int dtype, void* stream) {
+  FSS_REQUIRE(y && ytb && ylr && ycn && r, "null argument");
+  FSS_DTYPE_OK(dtype);
+  FSS_CHUNK_OK(c, dtype);
+  FSS_ALIGNED(y); FSS_ALIGNED(ytb); FSS_ALIGNED(ylr); FSS_ALIGNED(ycn); FSS_ALIGNED(r);
+  FSS_REQUIRE(n > 0 && h >= 4 && wd >= 4, "bad shape (h, w >= 4)");
+  const int cc = c / (dtype == FSS_F32 ? 4 : 8);
+  const size_t total = (size_t)n * (2 * h - 1) * (2 * wd - 1) * cc;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL(zoom2_conv_commute_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const float*)y, (const float*)ytb, (const float*)ylr, (const float*)ycn,
+                       (float*)r, n, h, wd, c);
+  else
+    hipLaunchKernelGGL(zoom2_conv_commute_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const bf16_t*)y, (const bf16_t*)ytb, (const bf16_t*)ylr, (const bf16_t*)ycn,
+                       (bf16_t*)r, n, h, wd, c);
   FSS_LAUNCH_CHECK();
   return 0;
 }

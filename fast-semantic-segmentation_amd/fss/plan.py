@@ -92,7 +92,7 @@ class Step(object):
 # that points into an activation buffer is read)
 _OUT_ARGS = {
     'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,), 'fss_conv2d_dual_nhwc': (7,),
-    'fss_conv2d_dual_head_nhwc': (9,),
+    'fss_conv2d_dual_head_nhwc': (10,), 'fss_zoom2_border_gather': (1, 2, 3), 'fss_zoom2_conv_commute': (4,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
     'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1,), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
     'fss_add_act': (2,), 'fss_copy_channels': (2,), 'fss_upsample_argmax': (1, 2),
@@ -470,7 +470,7 @@ class CompiledGraph(object):
             return None
         return c
 
-    def _emit_head(self, head, d, x, x2, cin2, wdev, bdev, cout, k, name):
+    def _emit_head(self, head, d, x, x2, cin2, wdev, bdev, cout, k, name, res=None):
         """Emits conv (+ second input) + classifier `head` as one launch; the activated
         cout-channel tensor gets no buffer."""
         n, ho, wo, ncls = head.shape
@@ -491,7 +491,8 @@ class CompiledGraph(object):
         self._emit('conv', name + '+' + head.attrs['weights'].rsplit('/', 2)[-2],
                    'fss_conv2d_dual_head_nhwc',
                    (ctypes.byref(d), x.ptr, x2.ptr if x2 is not None else None, cin2, wdev.data_ptr(),
-                    bdev.data_ptr(), whdev.data_ptr(), bhdev.data_ptr(), ncls, out.ptr, out.ld, self.sh),
+                    bdev.data_ptr(), res.ptr if res is not None else None, whdev.data_ptr(),
+                    bhdev.data_ptr(), ncls, out.ptr, out.ld, self.sh),
                    flops=2 * n * ho * wo * cout * (k + ncls), nbytes=nbytes, keep=d)
 
     def _l_conv_dual(self, A, B):
@@ -949,7 +950,7 @@ class CompiledGraph(object):
                 key += ',%d,%d,dual%d' % (s.args[6] is not None, self.mfma_edge, s.args[3])
             elif fname == 'fss_conv2d_dual_head_nhwc':
                 # the N tile must hold every output channel (16x16 MFMA shape only)
-                key += ',head%d,%d,dual%d' % (s.args[8], self.mfma_edge, s.args[3])
+                key += ',head%d,%d,dual%d,%d' % (s.args[9], self.mfma_edge, s.args[3], s.args[6] is not None)
                 cands = [c for c in candidates if tile_n[c] >= max(d.cout, 128)]
             else:
                 key += ',%d,%d' % (s.args[4] is not None, self.mfma_edge)

@@ -129,7 +129,7 @@ int fss_conv2d_dual_nhwc(const fss_conv_desc* desc, const void* x, const void* x
                          void* y, void* stream);
 
 /* Convolution (one or two inputs, as above) followed by a 1x1 classifier, in one launch:
- *   y_head[m][c] = bias_head[c] + sum_n bf16(act(conv(x, W) + conv1x1(x2, W2) + bias))[m][n] * w_head[c][n]
+ *   y_head[m][c] = bias_head[c] + sum_n bf16(act(conv(x, W) + conv1x1(x2, W2) + bias + residual))[m][n] * w_head[c][n]
  * The activated cout-channel tensor is never stored; only the cout_head class scores per
  * pixel leave the kernel (float32, pixel stride y_head_ld).  Replaces the last cascade
  * feature fusion + the `Predictions` slim.conv2d of architectures/icnet_architecture.py:
@@ -137,12 +137,31 @@ int fss_conv2d_dual_nhwc(const fss_conv_desc* desc, const void* x, const void* x
  * 1x1 convolution).  bf16 activations only; cin (and cin2) multiples of 64; cout a multiple
  * of 32 and <= 256; cout_head <= 20; w_head: bf16 [32][cout], rows >= cout_head zero;
  * desc->config: 0 or a 16x16-MFMA configuration whose block columns >= cout;
- * desc->out_dtype, y_ld, res_ld are ignored.  Equals fss_conv2d_dual_nhwc followed by
+ * `residual`: bf16 [pixels][cout] with pixel stride desc->res_ld, or NULL.
+ * desc->out_dtype and y_ld are ignored.  Equals fss_conv2d_dual_nhwc followed by
  * fss_conv2d_nhwc up to float summation order. */
 int fss_conv2d_dual_head_nhwc(const fss_conv_desc* desc, const void* x, const void* x2, int cin2,
-                              const void* w_packed, const float* bias, const void* w_head,
-                              const float* bias_head, int cout_head, float* y_head,
-                              int y_head_ld, void* stream);
+                              const void* w_packed, const float* bias, const void* residual,
+                              const void* w_head, const float* bias_head, int cout_head,
+                              float* y_head, int y_head_ld, void* stream);
+
+/* Pieces of  conv3x3_dilation2(zoom_x2(x)) = zoom_x2(conv3x3(x))  (align_corners zoom to
+ * (2h-1, 2w-1), zero padding, both sides linear in x), which holds everywhere except on
+ * output rows / columns 1 and 2h-3 / 2w-3: there one of the source results that the zoom
+ * averages must be computed without the border row / column of x, because the tap that
+ * reaches it lands on the zero padding of the zoomed map.  Used for the dilated convolution
+ * of the cascade feature fusion (architectures/icnet_architecture.py:238-247), which then
+ * runs on a quarter of the pixels.
+ *   fss_zoom2_border_gather: crops of x [n,h,w,c] with that row / column zeroed:
+ *     tb [2n,3,w,c] (top rows 0-2 with row 0 zero; bottom rows h-3..h-1 with the last zero),
+ *     lr [2n,h,3,c] (left, right likewise), cn [4n,3,3,c] (corners TL, TR, BL, BR, both zero).
+ *   The caller convolves x, tb, lr, cn with the same 3x3 filter (dilation 1, padding 1).
+ *   fss_zoom2_conv_commute: r [n,2h-1,2w-1,c] = zoom_x2(y) with the middle row / column /
+ *     pixel of ytb / ylr / ycn substituted where the identity needs them.  h, w >= 4. */
+int fss_zoom2_border_gather(const void* x, void* tb, void* lr, void* cn, int n, int h, int w, int c,
+                            int dtype, void* stream);
+int fss_zoom2_conv_commute(const void* y, const void* ytb, const void* ylr, const void* ycn, void* r,
+                           int n, int h, int w, int c, int dtype, void* stream);
 
 /* Depthwise 3x3-style convolution + bias + activation.
  * Replaces slim.separable_conv2d(num_outputs=None) + batch_norm + relu6

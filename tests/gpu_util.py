@@ -102,7 +102,7 @@ def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, 
 
 
 def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), out_hw=None, act='relu',
-                     config=0, y_ld=None):
+                     config=0, y_ld=None, residual=None):
     """bf16(act(conv(x, w) + conv1x1(x2, w2) + bias)) times the [cout, classes] matrix w_head
     + b_head through fss_conv2d_dual_head_nhwc (bfloat16 activations); x2 / w2 may be None.
     Returns float32 [n,ho,wo,classes]."""
@@ -125,21 +125,54 @@ def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), ou
     x2d = to_dev(x2, 'bf16') if cin2 else None
     bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda()
     bh = torch.from_numpy(np.asarray(b_head, np.float32)).cuda()
+    rd = to_dev(residual, 'bf16') if residual is not None else None
     ld = y_ld or ncls
     y = torch.full((n, ho, wo, ld), -77.0, dtype=torch.float32, device='cuda')
     d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
                       dilation=rate, pad_top=pads[0], pad_left=pads[1], ho=ho, wo=wo,
                       act=_lib.ACT_CODES[act], in_dtype=_lib.BF16, out_dtype=_lib.BF16,
-                      y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad, config=config)
+                      y_ld=cout, res_ld=cout, k_pad=k_pad, cout_pad=cout_pad, config=config)
     torch.cuda.synchronize()
     _lib.call('fss_conv2d_dual_head_nhwc', ctypes.byref(d), xd.data_ptr(),
               x2d.data_ptr() if cin2 else None, cin2, wdev.data_ptr(), bd.data_ptr(),
-              whdev.data_ptr(), bh.data_ptr(), ncls, y.data_ptr(), ld, None)
+              rd.data_ptr() if rd is not None else None, whdev.data_ptr(), bh.data_ptr(), ncls,
+              y.data_ptr(), ld, None)
     _lib.call('fss_device_sync')
     out = to_host(y)
     if ld != ncls:
         assert np.all(out[..., ncls:] == -77.0), 'kernel wrote outside its channel slice'
     return out[..., :ncls]
+
+
+def zoomed_dilated_conv(x, w, dt='f32'):
+    """conv3x3 with dilation 2 (SAME) of the align_corners x2 zoom of x, computed at the source
+    resolution: fss_zoom2_border_gather, four fss_conv2d_nhwc launches (x and the three crop
+    tensors, same filter, dilation 1), fss_zoom2_conv_commute.  Returns float32
+    [n,2h-1,2w-1,cout]."""
+    n, h, wd, cin = x.shape
+    cout = w.shape[3]
+    code, tdt, _ = DT[dt]
+    xd = to_dev(x, dt)
+    wdev, k_pad, cout_pad = pack_conv_weights(w, dt)
+    mk = lambda *shape: torch.full(shape, -77.0, dtype=tdt, device='cuda')
+    tb, lr, cn = mk(2 * n, 3, wd, cin), mk(2 * n, h, 3, cin), mk(4 * n, 3, 3, cin)
+    _lib.call('fss_zoom2_border_gather', xd.data_ptr(), tb.data_ptr(), lr.data_ptr(), cn.data_ptr(),
+              n, h, wd, cin, code, None)
+    outs = []
+    for t in (xd, tb, lr, cn):
+        nn, hh, ww, _ = t.shape
+        y = mk(nn, hh, ww, cout)
+        d = _lib.ConvDesc(n=nn, h=hh, w=ww, cin=cin, cout=cout, kh=3, kw=3, stride=1, dilation=1,
+                          pad_top=1, pad_left=1, ho=hh, wo=ww, act=_lib.ACT_CODES[None], in_dtype=code,
+                          out_dtype=code, y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad, config=0)
+        _lib.call('fss_conv2d_nhwc', ctypes.byref(d), t.data_ptr(), wdev.data_ptr(), None, None,
+                  y.data_ptr(), None)
+        outs.append(y)
+    r = mk(n, 2 * h - 1, 2 * wd - 1, cout)
+    _lib.call('fss_zoom2_conv_commute', outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+              outs[3].data_ptr(), r.data_ptr(), n, h, wd, cout, code, None)
+    _lib.call('fss_device_sync')
+    return to_host(r)
 
 
 def pack_stem_weights(w, dt):

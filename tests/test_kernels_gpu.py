@@ -157,8 +157,8 @@ def test_conv2d_dual_is_the_sum_of_two_convolutions(dt):
             assert np.array_equal(out, first), 'config %d differs inside its shape class' % cfg
 
 
-@pytest.mark.parametrize('cout,cin2', [(256, 64), (128, 0), (96, 128)])
-def test_conv2d_head_is_conv_then_classifier(cout, cin2):
+@pytest.mark.parametrize('cout,cin2,with_res', [(256, 64, False), (128, 0, True), (96, 128, False)])
+def test_conv2d_head_is_conv_then_classifier(cout, cin2, with_res):
     """fss_conv2d_dual_head_nhwc = the two-input convolution, rounded to bfloat16 as the
     unfused plan stores it, followed by the 1x1 classifier, against the oracle in float64;
     every configuration that can hold the layer must agree to float summation order, the
@@ -177,6 +177,10 @@ def test_conv2d_head_is_conv_then_classifier(cout, cin2):
     bias = rng.normal(0, 1, cout).astype(np.float32)
     w_head = gu.bf16_round(rng.normal(0, 0.1, (cout, ncls)).astype(np.float32))
     b_head = rng.normal(0, 1, ncls).astype(np.float32)
+    res = None
+    if with_res:
+        res = gu.bf16_round(rng.normal(0, 1, (n, h, wd, cout)).astype(np.float32))
+        conv = conv + res
     act = gu.bf16_round(O.relu(conv + bias).astype(np.float32)).astype(np.float64)
     ref = act.reshape(-1, cout) @ w_head.astype(np.float64) + b_head
     ref = ref.reshape(n, h, wd, ncls)
@@ -190,13 +194,38 @@ def test_conv2d_head_is_conv_then_classifier(cout, cin2):
                 gu.conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, 2, (2, 2), (h, wd), config=cfg)
             continue
         out = gu.conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, 2, (2, 2), (h, wd), config=cfg,
-                                  y_ld=20 if cfg % 2 else None)
+                                  y_ld=20 if cfg % 2 else None, residual=res)
         # a bfloat16 rounding of an activation that sits on a tie may go the other way
         # (the conv sum is formed in another order than the oracle's): 2^-8 * |w_head| * act
         _close(out, ref, 2e-2, 'head conv config %d' % cfg)
         assert np.mean(np.abs(out - ref) > 2e-3) < 0.01, 'config %d' % cfg
         ran += 1
     assert ran >= 3
+
+
+@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 4, 4, 8, 24), (1, 5, 9, 16, 40), (2, 33, 17, 64, 64)])
+def test_dilated_conv_of_a_zoom_at_the_source_resolution(shape, dt):
+    """conv3x3_dilation2(zoom_x2(x)) from fss_zoom2_border_gather + the plain conv3x3 of x and
+    of its border crops + fss_zoom2_conv_commute, against the oracle's zoom followed by the
+    dilated convolution (float64), including the smallest legal map (4x4) where every output
+    pixel is near a border."""
+    gu = _gu()
+    n, h, wd, cin, cout = shape
+    rng = np.random.default_rng(31)
+    x = rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32)
+    w = rng.normal(0, 0.1, (3, 3, cin, cout)).astype(np.float32)
+    if dt == 'bf16':
+        x, w = gu.bf16_round(x), gu.bf16_round(w)
+    up = O.resize_bilinear(x.astype(np.float64), 2 * h - 1, 2 * wd - 1, True)
+    ref = O.conv2d(up, w, 1, 2, 'SAME', np.float64)
+    out = gu.zoomed_dilated_conv(x, w, dt)
+    assert out.shape == ref.shape
+    # bf16: the source-resolution results are rounded to bfloat16 before they are averaged
+    _close(out, ref, 2e-5 if dt == 'f32' else 1.0 / 128, 'zoomed dilated conv')
+    if dt == 'f32':     # the border rows / columns are as exact as the interior
+        for sl in (np.s_[:, 1], np.s_[:, -2], np.s_[:, :, 1], np.s_[:, :, -2]):
+            _close(out[sl], ref[sl], 2e-5, 'border')
 
 
 def test_entry_points_reject_bad_arguments():
@@ -242,14 +271,14 @@ def test_entry_points_reject_bad_arguments():
                                          x.data_ptr(), 32, w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None)
     # classifier-head form: bfloat16, at most 20 classes, a 16x16-MFMA configuration
     yh = torch.zeros((1, 8, 8, 20), dtype=torch.float32, device='cuda')
-    head = [x.data_ptr(), None, 0, w.data_ptr(), b.data_ptr(), w.data_ptr(), b.data_ptr(), 19, yh.data_ptr(),
-            20, None]
+    head = [x.data_ptr(), None, 0, w.data_ptr(), b.data_ptr(), None, w.data_ptr(), b.data_ptr(), 19,
+            yh.data_ptr(), 20, None]
     assert L.lib.fss_conv2d_dual_head_nhwc(ctypes.byref(good), *head) == 0
-    bad = list(head); bad[7] = 21
+    bad = list(head); bad[8] = 21
     assert 'cout_head' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
-    bad = list(head); bad[9] = 16
+    bad = list(head); bad[10] = 16
     assert 'y_head_ld' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
-    bad = list(head); bad[5] = None
+    bad = list(head); bad[6] = None
     assert 'null' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
     assert 'bf16' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(desc(in_dtype=L.F32, out_dtype=L.F32)),
                               *head)
