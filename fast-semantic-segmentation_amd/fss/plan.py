@@ -110,7 +110,7 @@ class CompiledGraph(object):
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
                  fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True,
-                 fuse_head=True, collapse_zooms=True):
+                 fuse_head=True, collapse_zooms=True, commute_zoom=None):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
@@ -124,6 +124,7 @@ class CompiledGraph(object):
         self.vals = {}          # LNode -> Val
         self.lazy = {}          # LNode -> (tag, info..., materialise closure)
         self.keepalive = []     # device-side constants (packed weights, biases, tables)
+        self.temps = []         # activation buffers between launches that stand for one graph node
         self.input_val = None
         self.graph_exec = None
         self.param_bytes = 0
@@ -137,6 +138,7 @@ class CompiledGraph(object):
         self.fuse_dual = fuse_dual
         self.fuse_head = fuse_head
         self.collapse_zooms = collapse_zooms
+        self.commute_zoom = commute_zoom
         self.dual = {}          # 1x1 conv node -> the conv whose output it is added to (one launch)
         self.two_streams = False
         self.release_after = None
@@ -487,7 +489,8 @@ class CompiledGraph(object):
         self.vals[head] = out
         self.fused.add(head)
         nbytes = ((x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] + n * ho * wo * cin2 + cout * k
-                   + cout * ncls) * 2 + n * ho * wo * ncls * 4)
+                   + cout * ncls + (n * ho * wo * cout if res is not None else 0)) * 2
+                  + n * ho * wo * ncls * 4)
         self._emit('conv', name + '+' + head.attrs['weights'].rsplit('/', 2)[-2],
                    'fss_conv2d_dual_head_nhwc',
                    (ctypes.byref(d), x.ptr, x2.ptr if x2 is not None else None, cin2, wdev.data_ptr(),
@@ -495,8 +498,121 @@ class CompiledGraph(object):
                     bhdev.data_ptr(), ncls, out.ptr, out.ld, self.sh),
                    flops=2 * n * ho * wo * cout * (k + ncls), nbytes=nbytes, keep=d)
 
+    def _zoom_source(self, B):
+        """The low-resolution node x when conv B is conv3x3, dilation 2, stride 1, SAME of a
+        deferred align_corners zoom of x to (2h-1, 2w-1) that nothing else reads (the dilated
+        convolution of a cascade feature fusion, architectures/icnet_architecture.py:238-247)."""
+        # None: only from FSS_COMMUTE_MIN_BATCH frames per launch on (the six extra launches
+        # cost more than the saved FLOP at small batches)
+        if self.commute_zoom is False:
+            return None
+        if self.commute_zoom is None and B.shape[0] < int(os.environ.get('FSS_COMMUTE_MIN_BATCH', '8')):
+            return None
+        b, src = B.attrs, B.inputs[0]
+        d = self.lazy.get(src)
+        if not d or d[0] != 'resize' or not d[2] or src.is_output or len(src.consumers) != 1:
+            return None
+        if (b['kh'], b['kw'], b['stride'], b['rate'], b['pad_top'], b['pad_left']) != (3, 3, 1, 2, 2, 2):
+            return None
+        low = d[1]
+        _, h, w, c = low.shape
+        if h < 4 or w < 4 or tuple(src.shape[1:3]) != (2 * h - 1, 2 * w - 1) or B.shape[:3] != src.shape[:3]:
+            return None
+        return low
+
+    def _l_conv_dual_commuted(self, A, B, xl, x2):
+        """relu?(conv3x3_d2(zoom_x2(xl)) + conv1x1(x2)) with the 3x3 computed at xl's resolution:
+        zoom and convolution are both linear, so conv3x3_d2(zoom(xl)) = zoom(conv3x3(xl)) except
+        on the output rows / columns next to the border ring, which fss_zoom2_conv_commute
+        takes from convolutions of border crops of xl (see include/fss.h).  The 1x1 launch then
+        adds the zoomed result as its residual."""
+        dt = xl.dt
+        b = B.attrs
+        n, h, w, cin = xl.shape
+        _, ho, wo, cout = B.shape
+        cin2 = x2.shape[3]
+        add = A.consumers[0]
+        act, result = None, add
+        self.fused.add(add)
+        relu = self._only_consumer(add, 'relu')
+        if relu is not None:
+            act, result = 'relu', relu
+            self.fused.add(relu)
+        sB, bB = self._fold_bn(b, cout)
+        sA, bA = self._fold_bn(A.attrs, cout)
+
+        def pack(Wt, k):
+            k_pad, cout_pad = (k + 63) // 64 * 64, (cout + 255) // 256 * 256
+            Wp = np.zeros((cout_pad, k_pad), np.float32)
+            Wp[:cout, :k] = Wt
+            if dt == 'bf16':
+                dev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+            else:
+                dev = torch.from_numpy(Wp).to(self.device)
+            self.keepalive.append(dev)
+            return dev, k_pad, cout_pad
+
+        WB = (self.weights[b['weights']].astype(np.float64) * sB).transpose(3, 0, 1, 2).reshape(cout, -1)
+        wB, k_pad, cout_pad = pack(WB, 9 * cin)
+        self.param_bytes += cout * (9 * cin + cin2) * _ESZ[dt]
+        base = b['weights'].rsplit('/', 1)[0]
+        esz = _ESZ[dt]
+        tb = Val(self._alloc((2 * n, 3, w, cin), dt), (2 * n, 3, w, cin), dt)
+        lr = Val(self._alloc((2 * n, h, 3, cin), dt), (2 * n, h, 3, cin), dt)
+        cn = Val(self._alloc((4 * n, 3, 3, cin), dt), (4 * n, 3, 3, cin), dt)
+        crop_px = 2 * n * 3 * w + 2 * n * h * 3 + 4 * n * 9
+        self._emit('copy', base + '/border_crops', 'fss_zoom2_border_gather',
+                   (xl.ptr, tb.ptr, lr.ptr, cn.ptr, n, h, w, cin, _CODE[dt], self.sh),
+                   nbytes=2 * crop_px * cin * esz)
+        ys = []
+        for tag, v in (('@source', xl), ('@rows', tb), ('@columns', lr), ('@corners', cn)):
+            nn, hh, ww, _ = v.shape
+            y = Val(self._alloc((nn, hh, ww, cout), dt), (nn, hh, ww, cout), dt)
+            d = _lib.ConvDesc(n=nn, h=hh, w=ww, cin=cin, cout=cout, kh=3, kw=3, stride=1, dilation=1,
+                              pad_top=1, pad_left=1, ho=hh, wo=ww, act=_lib.ACT_CODES[None],
+                              in_dtype=_CODE[dt], out_dtype=_CODE[dt], y_ld=y.ld, res_ld=0,
+                              k_pad=k_pad, cout_pad=cout_pad)
+            self._emit('conv', base + tag, 'fss_conv2d_nhwc',
+                       (ctypes.byref(d), v.ptr, wB.data_ptr(), None, None, y.ptr, self.sh),
+                       flops=2 * nn * hh * ww * cout * 9 * cin,
+                       nbytes=(nn * hh * ww * (cin + cout) + cout * 9 * cin) * esz, keep=d)
+            ys.append(y)
+        r = Val(self._alloc((n, ho, wo, cout), dt), (n, ho, wo, cout), dt)
+        self._emit('resize', base + '/zoom', 'fss_zoom2_conv_commute',
+                   (ys[0].ptr, ys[1].ptr, ys[2].ptr, ys[3].ptr, r.ptr, n, h, w, cout, _CODE[dt], self.sh),
+                   nbytes=(n * h * w + n * ho * wo) * cout * esz)
+        self.temps.extend([tb, lr, cn, r] + ys)     # buffers no graph node owns
+        # the 1x1 half, with the zoomed 3x3 half as its residual
+        WA = (self.weights[A.attrs['weights']].astype(np.float64) * sA).reshape(cin2, cout).T
+        wA, k_pad2, _ = pack(WA, cin2)
+        bdev = self._dev_f32(bA + bB)
+        name = base + '+' + A.attrs['weights'].rsplit('/', 2)[-2]
+        head = self._head_partner(result, cout, dt) if cin2 % 64 == 0 else None
+        d = _lib.ConvDesc(n=n, h=ho, w=wo, cin=cin2, cout=cout, kh=1, kw=1, stride=1, dilation=1,
+                          pad_top=0, pad_left=0, ho=ho, wo=wo, act=_lib.ACT_CODES[act],
+                          in_dtype=_CODE[dt], out_dtype=_CODE[dt], y_ld=cout, res_ld=r.ld,
+                          k_pad=k_pad2, cout_pad=cout_pad)
+        if head is not None:
+            return self._emit_head(head, d, x2, None, 0, wA, bdev, cout, cin2, name, res=r)
+        out = Val(self._alloc(B.shape, dt), B.shape, dt)
+        for node in (A, B, add, result):
+            self.vals[node] = out
+        d.y_ld = out.ld
+        self._emit('conv', name, 'fss_conv2d_nhwc',
+                   (ctypes.byref(d), x2.ptr, wA.data_ptr(), bdev.data_ptr(), r.ptr, out.ptr, self.sh),
+                   flops=2 * n * ho * wo * cout * cin2,
+                   nbytes=(n * ho * wo * (cin2 + 2 * cout) + cout * cin2) * esz, keep=d)
+
     def _l_conv_dual(self, A, B):
         """relu?(conv B + conv1x1 A) in one launch; A is the node being lowered."""
+        low = self._zoom_source(B)
+        if low is not None:
+            xl, x2 = self._val(low), self._val(A.inputs[0])
+            if (xl.dense and x2.dense and xl.dt == x2.dt == self.dt and xl.phys_c == low.shape[3]
+                    and x2.phys_c == A.inputs[0].shape[3] and xl.phys_c % _EPC[xl.dt] == 0
+                    and B.shape[3] % _EPC[xl.dt] == 0):
+                self.lazy.pop(B.inputs[0])
+                return self._l_conv_dual_commuted(A, B, xl, x2)
         x, x2 = self._val(B.inputs[0]), self._val(A.inputs[0])
         if not (x.dense and x2.dense and x.dt == x2.dt and x.phys_c % 64 == 0 and x2.phys_c % 64 == 0
                 and x.phys_c == B.inputs[0].shape[3] and x2.phys_c == A.inputs[0].shape[3]):
@@ -986,7 +1102,7 @@ class CompiledGraph(object):
         activation buffers each launch reads and writes (pointer arguments that fall
         inside a buffer of the plan; _OUT_ARGS says which of them are written)."""
         ranges, seen = [], set()
-        for v in list(self.vals.values()) + [self.input_val]:
+        for v in list(self.vals.values()) + self.temps + [self.input_val]:
             t = v.buf
             if t.data_ptr() not in seen:
                 seen.add(t.data_ptr())

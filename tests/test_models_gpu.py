@@ -305,7 +305,8 @@ def test_side_stream_and_stem_fusion_do_not_change_results(dtype):
 def test_layer_fusions_agree_with_the_unfused_plan(dtype):
     """Each cross-layer fusion of the plan compiler (the two stride-2 convolutions of the
     full-resolution branch in one kernel; the sum of two convolutions as one GEMM; the
-    classifier in the epilogue of the last convolution) is
+    classifier in the epilogue of the last convolution; the dilated convolution of a cascade
+    feature fusion computed in front of the x2 zoom) is
     switched off in turn; logits must agree with the fully fused plan to rounding (the
     fused forms keep float32 where the unfused ones round an intermediate to the storage
     type, so bfloat16 differs by at most a few bf16 steps of the logit scale)."""
@@ -313,7 +314,7 @@ def test_layer_fusions_agree_with_the_unfused_plan(dtype):
     arch, ext, fs, pf, in_shape, pad_shape = CASES[0]
     g, cfg, outs, weights = build(arch, ext, fs, pf, in_shape, pad_shape)
     img = np.random.default_rng(5).integers(0, 256, in_shape).astype(np.uint8)
-    ref_plan = plan.CompiledGraph(g, outs, weights, dtype=dtype, streams=1)
+    ref_plan = plan.CompiledGraph(g, outs, weights, dtype=dtype, streams=1, commute_zoom=True)
     kinds = [s.kind for s in ref_plan.steps]
     fnames = list(ref_plan.step_fname)
     assert 'fss_conv2d_dual_nhwc' in fnames, 'ICNet must use the two-input convolution'
@@ -322,11 +323,15 @@ def test_layer_fusions_agree_with_the_unfused_plan(dtype):
         assert 'fss_conv2d_dual_head_nhwc' in fnames, 'ICNet in bfloat16 must fuse the classifier'
     ref = ref_plan.run(img)[0]
     scale = float(np.abs(ref).max())
-    for kw in (dict(fuse_stem2=False), dict(fuse_dual=False), dict(fuse_head=False),
-               dict(fuse_stem2=False, fuse_dual=False, fuse_head=False)):
+    assert 'fss_zoom2_conv_commute' in fnames, 'ICNet must run the fusion\'s dilated conv before the zoom'
+    for kw in (dict(fuse_stem2=False), dict(fuse_dual=False), dict(fuse_head=False), dict(commute_zoom=False),
+               dict(fuse_stem2=False, fuse_dual=False, fuse_head=False, commute_zoom=False)):
+        kw.setdefault('commute_zoom', True)
         cg = plan.CompiledGraph(g, outs, weights, dtype=dtype, streams=1, **kw)
         if not kw.get('fuse_head', True):
             assert 'fss_conv2d_dual_head_nhwc' not in cg.step_fname
+        if not kw.get('commute_zoom', True):
+            assert 'fss_zoom2_conv_commute' not in cg.step_fname
         if not kw.get('fuse_dual', True):
             assert 'fss_conv2d_dual_nhwc' not in cg.step_fname
         if not kw.get('fuse_stem2', True):
@@ -350,7 +355,7 @@ def test_every_launch_writes_only_its_own_outputs():
     cg = plan.CompiledGraph(g, outs, weights, dtype='bfloat16', streams=1, use_hip_graph=False)
     cg.run(np.random.default_rng(4).integers(0, 256, in_shape).astype(np.uint8))
     bufs = {}
-    for v in list(cg.vals.values()) + [cg.input_val]:
+    for v in list(cg.vals.values()) + cg.temps + [cg.input_val]:
         bufs[v.buf.data_ptr()] = v.buf
 
     def buf_of(ptr):
