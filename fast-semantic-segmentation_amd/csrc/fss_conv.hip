@@ -66,6 +66,13 @@ struct ConvArgs {
   const void* w_head;       // bf16 [32][Cout], rows >= cout_head zero
   const float* bias_head;   // [cout_head]
   int cout_head;
+  // residual of the HEAD kernels given as the x2 zoom of a half-resolution tensor zy[N][zH][zW][Cout]
+  // (+ the border substitutes of fss_zoom2_conv_commute), interpolated in the epilogue
+  const void* zy;
+  const void* zytb;
+  const void* zylr;
+  const void* zycn;
+  int zH, zW;
 };
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -442,7 +449,43 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         f32x4 d0 = acc[i][2 * s], d1 = acc[i][2 * s + 1];
-        if (a.res != nullptr) {
+        if (a.zy != nullptr) {
+          // residual = corrected x2 zoom of zy at this lane's pixel: mean of 1, 2 or 4 sources
+          const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
+          if (m < a.M) {
+            const int f = m / HoWo, rem = m - f * HoWo;
+            const int p = rem / a.Wo, q = rem - p * a.Wo;
+            const int i0 = p >> 1, j0 = q >> 1, ni = 1 + (p & 1), nj = 1 + (q & 1);
+            float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+              const int da = nb >> 1, db = nb & 1;
+              if (da < ni && db < nj) {
+                const int zi = i0 + da, zj = j0 + db;
+                const int rf = (p == 1 && zi == 1) ? 1 : (p == a.Ho - 2 && zi == a.zH - 2) ? 2 : 0;
+                const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
+                const T* src;
+                if (rf == 0 && cf == 0)
+                  src = reinterpret_cast<const T*>(a.zy) + (((size_t)f * a.zH + zi) * a.zW + zj) * a.Cout;
+                else if (cf == 0)
+                  src = reinterpret_cast<const T*>(a.zytb) + ((((size_t)(rf - 1) * a.N + f) * 3 + 1) * a.zW + zj) * a.Cout;
+                else if (rf == 0)
+                  src = reinterpret_cast<const T*>(a.zylr) + ((((size_t)(cf - 1) * a.N + f) * a.zH + zi) * 3 + 1) * a.Cout;
+                else
+                  src = reinterpret_cast<const T*>(a.zycn) + (((size_t)((rf - 1) * 2 + (cf - 1)) * a.N + f) * 9 + 4) * a.Cout;
+                src += c0 + 4 * lg;
+                const uint2 u0 = *reinterpret_cast<const uint2*>(src), u1 = *reinterpret_cast<const uint2*>(src + 16);
+                r0[0] += __uint_as_float(u0.x << 16); r0[1] += __uint_as_float(u0.x & 0xffff0000u);
+                r0[2] += __uint_as_float(u0.y << 16); r0[3] += __uint_as_float(u0.y & 0xffff0000u);
+                r1[0] += __uint_as_float(u1.x << 16); r1[1] += __uint_as_float(u1.x & 0xffff0000u);
+                r1[2] += __uint_as_float(u1.y << 16); r1[3] += __uint_as_float(u1.y & 0xffff0000u);
+              }
+            }
+            const float sc = 1.0f / (float)(ni * nj);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * sc; d1[e] += r1[e] * sc; }
+          }
+        } else if (a.res != nullptr) {
           const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
           if (m < a.M) {
             const T* rp = reinterpret_cast<const T*>(a.res) + (size_t)m * a.res_ld + c0 + 4 * lg;
@@ -818,6 +861,7 @@ static int conv_setup(const fss_conv_desc* d, const void* x, const void* x2, int
   a.Kpad = k_pad; a.y_ld = d->y_ld; a.res_ld = d->res_ld;
   a.tiles_m = a.tiles_n = 0;
   a.w_head = nullptr; a.bias_head = nullptr; a.cout_head = 0;
+  a.zy = a.zytb = a.zylr = a.zycn = nullptr; a.zH = a.zW = 0;
   FSS_REQUIRE(d->config >= 0 && d->config <= kNumConvConfigs, "config out of range");
   return 0;
 }
@@ -835,6 +879,7 @@ extern "C" int fss_conv2d_dual_nhwc(const fss_conv_desc* d, const void* x, const
 
 extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, const void* x2, int cin2,
                                          const void* w_packed, const float* bias, const void* residual,
+                                         const void* const* zoom_residual, int zh, int zw,
                                          const void* w_head, const float* bias_head, int cout_head,
                                          float* y_head, int y_head_ld, void* stream) {
   FSS_REQUIRE(d && w_head && y_head, "null argument");
@@ -853,6 +898,16 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
   const int bk = 64;        // widest K tile in elements (128-byte tile rows of bf16)
   FSS_REQUIRE(a.Cin % bk == 0 && a.Cin2 % bk == 0 && a.KH * a.KW <= 62,
               "the classifier-head form needs cin (and cin2) in multiples of 64");
+  if (zoom_residual != nullptr) {
+    FSS_REQUIRE(residual == nullptr, "residual and zoom_residual exclude each other");
+    FSS_REQUIRE(zh >= 4 && zw >= 4 && d->ho == 2 * zh - 1 && d->wo == 2 * zw - 1,
+                "zoom_residual: the output must be (2 zh - 1) x (2 zw - 1), zh, zw >= 4");
+    for (int i = 0; i < 4; ++i)
+      FSS_REQUIRE(zoom_residual[i] != nullptr && ((uintptr_t)zoom_residual[i] & 7) == 0,
+                  "zoom_residual: null or unaligned tensor");
+    a.zy = zoom_residual[0]; a.zytb = zoom_residual[1]; a.zylr = zoom_residual[2]; a.zycn = zoom_residual[3];
+    a.zH = zh; a.zW = zw;
+  }
   a.y = y_head; a.y_ld = y_head_ld;
   a.w_head = w_head; a.bias_head = bias_head; a.cout_head = cout_head;
   return dispatch_conv_head(a, d->config, (hipStream_t)stream);

@@ -92,7 +92,7 @@ class Step(object):
 # that points into an activation buffer is read)
 _OUT_ARGS = {
     'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,), 'fss_conv2d_dual_nhwc': (7,),
-    'fss_conv2d_dual_head_nhwc': (10,), 'fss_zoom2_border_gather': (1, 2, 3), 'fss_zoom2_conv_commute': (4,),
+    'fss_conv2d_dual_head_nhwc': (13,), 'fss_zoom2_border_gather': (1, 2, 3), 'fss_zoom2_conv_commute': (4,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
     'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1,), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
     'fss_add_act': (2,), 'fss_copy_channels': (2,), 'fss_upsample_argmax': (1, 2),
@@ -110,7 +110,7 @@ class CompiledGraph(object):
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
                  fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True,
-                 fuse_head=True, collapse_zooms=True, commute_zoom=None):
+                 fuse_head=True, collapse_zooms=True, commute_zoom=None, fuse_zoom_residual=None):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
@@ -139,6 +139,8 @@ class CompiledGraph(object):
         self.fuse_head = fuse_head
         self.collapse_zooms = collapse_zooms
         self.commute_zoom = commute_zoom
+        self.fuse_zoom_residual = (os.environ.get('FSS_FUSE_ZOOM_RESIDUAL', '1') != '0'
+                                   if fuse_zoom_residual is None else fuse_zoom_residual)
         self.dual = {}          # 1x1 conv node -> the conv whose output it is added to (one launch)
         self.two_streams = False
         self.release_after = None
@@ -472,7 +474,7 @@ class CompiledGraph(object):
             return None
         return c
 
-    def _emit_head(self, head, d, x, x2, cin2, wdev, bdev, cout, k, name, res=None):
+    def _emit_head(self, head, d, x, x2, cin2, wdev, bdev, cout, k, name, res=None, zres=None):
         """Emits conv (+ second input) + classifier `head` as one launch; the activated
         cout-channel tensor gets no buffer."""
         n, ho, wo, ncls = head.shape
@@ -489,14 +491,17 @@ class CompiledGraph(object):
         self.vals[head] = out
         self.fused.add(head)
         nbytes = ((x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] + n * ho * wo * cin2 + cout * k
-                   + cout * ncls + (n * ho * wo * cout if res is not None else 0)) * 2
+                   + cout * ncls + (n * ho * wo * cout if res is not None else 0)
+                   + (sum(int(np.prod(v.shape)) for v in zres) if zres else 0)) * 2
                   + n * ho * wo * ncls * 4)
+        zptrs = (ctypes.c_void_p * 4)(*[v.ptr for v in zres]) if zres else None
         self._emit('conv', name + '+' + head.attrs['weights'].rsplit('/', 2)[-2],
                    'fss_conv2d_dual_head_nhwc',
                    (ctypes.byref(d), x.ptr, x2.ptr if x2 is not None else None, cin2, wdev.data_ptr(),
-                    bdev.data_ptr(), res.ptr if res is not None else None, whdev.data_ptr(),
+                    bdev.data_ptr(), res.ptr if res is not None else None, zptrs,
+                    zres[0].shape[1] if zres else 0, zres[0].shape[2] if zres else 0, whdev.data_ptr(),
                     bhdev.data_ptr(), ncls, out.ptr, out.ld, self.sh),
-                   flops=2 * n * ho * wo * cout * (k + ncls), nbytes=nbytes, keep=d)
+                   flops=2 * n * ho * wo * cout * (k + ncls), nbytes=nbytes, keep=(d, zptrs))
 
     def _zoom_source(self, B):
         """The low-resolution node x when conv B is conv3x3, dilation 2, stride 1, SAME of a
@@ -577,23 +582,28 @@ class CompiledGraph(object):
                        flops=2 * nn * hh * ww * cout * 9 * cin,
                        nbytes=(nn * hh * ww * (cin + cout) + cout * 9 * cin) * esz, keep=d)
             ys.append(y)
-        r = Val(self._alloc((n, ho, wo, cout), dt), (n, ho, wo, cout), dt)
-        self._emit('resize', base + '/zoom', 'fss_zoom2_conv_commute',
-                   (ys[0].ptr, ys[1].ptr, ys[2].ptr, ys[3].ptr, r.ptr, n, h, w, cout, _CODE[dt], self.sh),
-                   nbytes=(n * h * w + n * ho * wo) * cout * esz)
-        self.temps.extend([tb, lr, cn, r] + ys)     # buffers no graph node owns
+        self.temps.extend([tb, lr, cn] + ys)        # buffers no graph node owns
+        head = self._head_partner(result, cout, dt) if cin2 % 64 == 0 else None
+        r = None
+        if head is None or not self.fuse_zoom_residual:
+            r = Val(self._alloc((n, ho, wo, cout), dt), (n, ho, wo, cout), dt)
+            self._emit('resize', base + '/zoom', 'fss_zoom2_conv_commute',
+                       (ys[0].ptr, ys[1].ptr, ys[2].ptr, ys[3].ptr, r.ptr, n, h, w, cout, _CODE[dt], self.sh),
+                       nbytes=(n * h * w + n * ho * wo) * cout * esz)
+            self.temps.append(r)
         # the 1x1 half, with the zoomed 3x3 half as its residual
         WA = (self.weights[A.attrs['weights']].astype(np.float64) * sA).reshape(cin2, cout).T
         wA, k_pad2, _ = pack(WA, cin2)
         bdev = self._dev_f32(bA + bB)
         name = base + '+' + A.attrs['weights'].rsplit('/', 2)[-2]
-        head = self._head_partner(result, cout, dt) if cin2 % 64 == 0 else None
         d = _lib.ConvDesc(n=n, h=ho, w=wo, cin=cin2, cout=cout, kh=1, kw=1, stride=1, dilation=1,
                           pad_top=0, pad_left=0, ho=ho, wo=wo, act=_lib.ACT_CODES[act],
-                          in_dtype=_CODE[dt], out_dtype=_CODE[dt], y_ld=cout, res_ld=r.ld,
+                          in_dtype=_CODE[dt], out_dtype=_CODE[dt], y_ld=cout, res_ld=r.ld if r else 0,
                           k_pad=k_pad2, cout_pad=cout_pad)
         if head is not None:
-            return self._emit_head(head, d, x2, None, 0, wA, bdev, cout, cin2, name, res=r)
+            # the classifier launch interpolates the source-resolution results itself
+            return self._emit_head(head, d, x2, None, 0, wA, bdev, cout, cin2, name, res=r,
+                                   zres=None if r is not None else ys)
         out = Val(self._alloc(B.shape, dt), B.shape, dt)
         for node in (A, B, add, result):
             self.vals[node] = out
@@ -1059,14 +1069,15 @@ class CompiledGraph(object):
         for s, fname in zip(self.steps, self.step_fname):
             if s.kind != 'conv':
                 continue
-            d = s.keep
+            d = s.keep[0] if isinstance(s.keep, tuple) else s.keep
             key = ','.join(str(getattr(d, f[0])) for f in d._fields_ if f[0] != 'config')
             cands = candidates
             if fname == 'fss_conv2d_dual_nhwc':
                 key += ',%d,%d,dual%d' % (s.args[6] is not None, self.mfma_edge, s.args[3])
             elif fname == 'fss_conv2d_dual_head_nhwc':
                 # the N tile must hold every output channel (16x16 MFMA shape only)
-                key += ',head%d,%d,dual%d,%d' % (s.args[9], self.mfma_edge, s.args[3], s.args[6] is not None)
+                key += ',head%d,%d,dual%d,%d' % (s.args[12], self.mfma_edge, s.args[3],
+                                                 1 if s.args[6] is not None else 2 if s.args[7] is not None else 0)
                 cands = [c for c in candidates if tile_n[c] >= max(d.cout, 128)]
             else:
                 key += ',%d,%d' % (s.args[4] is not None, self.mfma_edge)
@@ -1352,5 +1363,6 @@ class CompiledGraph(object):
         for e in evs:
             _lib.call('fss_event_destroy', e)
         return [dict(kind=s.kind, name=s.name, ms=best[k], flops=s.flops, bytes=s.bytes,
-                     config=(s.keep.config if s.kind == 'conv' else None))
+                     config=((s.keep[0] if isinstance(s.keep, tuple) else s.keep).config
+                             if s.kind == 'conv' else None))
                 for k, s in enumerate(self.steps)]

@@ -138,10 +138,15 @@ int fss_conv2d_dual_nhwc(const fss_conv_desc* desc, const void* x, const void* x
  * of 32 and <= 256; cout_head <= 20; w_head: bf16 [32][cout], rows >= cout_head zero;
  * desc->config: 0 or a 16x16-MFMA configuration whose block columns >= cout;
  * `residual`: bf16 [pixels][cout] with pixel stride desc->res_ld, or NULL.
+ * `zoom_residual` (or NULL): the residual given at half resolution, as the four tensors
+ * {y, ytb, ylr, ycn} of fss_zoom2_conv_commute (bf16, cout channels, y: [n,zh,zw,cout]) and
+ * interpolated in the epilogue instead of being read from a zoomed copy; ho = 2 zh - 1,
+ * wo = 2 zw - 1.
  * desc->out_dtype and y_ld are ignored.  Equals fss_conv2d_dual_nhwc followed by
  * fss_conv2d_nhwc up to float summation order. */
 int fss_conv2d_dual_head_nhwc(const fss_conv_desc* desc, const void* x, const void* x2, int cin2,
                               const void* w_packed, const float* bias, const void* residual,
+                              const void* const* zoom_residual, int zh, int zw,
                               const void* w_head, const float* bias_head, int cout_head,
                               float* y_head, int y_head_ld, void* stream);
 

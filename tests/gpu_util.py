@@ -102,7 +102,7 @@ def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, 
 
 
 def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), out_hw=None, act='relu',
-                     config=0, y_ld=None, residual=None):
+                     config=0, y_ld=None, residual=None, zoom_residual=None):
     """bf16(act(conv(x, w) + conv1x1(x2, w2) + bias)) times the [cout, classes] matrix w_head
     + b_head through fss_conv2d_dual_head_nhwc (bfloat16 activations); x2 / w2 may be None.
     Returns float32 [n,ho,wo,classes]."""
@@ -126,6 +126,9 @@ def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), ou
     bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda()
     bh = torch.from_numpy(np.asarray(b_head, np.float32)).cuda()
     rd = to_dev(residual, 'bf16') if residual is not None else None
+    zd = [to_dev(t, 'bf16') for t in zoom_residual] if zoom_residual is not None else None
+    zp = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in zd]) if zd else None
+    zh, zw = (zd[0].shape[1], zd[0].shape[2]) if zd else (0, 0)
     ld = y_ld or ncls
     y = torch.full((n, ho, wo, ld), -77.0, dtype=torch.float32, device='cuda')
     d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
@@ -135,8 +138,8 @@ def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), ou
     torch.cuda.synchronize()
     _lib.call('fss_conv2d_dual_head_nhwc', ctypes.byref(d), xd.data_ptr(),
               x2d.data_ptr() if cin2 else None, cin2, wdev.data_ptr(), bd.data_ptr(),
-              rd.data_ptr() if rd is not None else None, whdev.data_ptr(), bh.data_ptr(), ncls,
-              y.data_ptr(), ld, None)
+              rd.data_ptr() if rd is not None else None, zp, zh, zw, whdev.data_ptr(), bh.data_ptr(),
+              ncls, y.data_ptr(), ld, None)
     _lib.call('fss_device_sync')
     out = to_host(y)
     if ld != ncls:

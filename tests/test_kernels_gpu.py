@@ -228,6 +228,49 @@ def test_dilated_conv_of_a_zoom_at_the_source_resolution(shape, dt):
             _close(out[sl], ref[sl], 2e-5, 'border')
 
 
+def test_head_conv_interpolates_its_residual_from_the_source_resolution():
+    """fss_conv2d_dual_head_nhwc with zoom_residual = {y, ytb, ylr, ycn}: the epilogue adds the
+    corrected x2 zoom of y (border rows / columns from the three substitute tensors) exactly
+    as fss_zoom2_conv_commute would have stored it; checked against the same entry point fed
+    with that stored residual and against float64."""
+    gu = _gu()
+    rng = np.random.default_rng(41)
+    n, zh, zw, cin, cout, ncls = 2, 6, 9, 64, 128, 19
+    h, wd = 2 * zh - 1, 2 * zw - 1
+    r16 = lambda *shape: gu.bf16_round(rng.normal(0, 1, shape).astype(np.float32))
+    x, w = r16(n, h, wd, cin), gu.bf16_round(rng.normal(0, 0.1, (1, 1, cin, cout)).astype(np.float32))
+    y, ytb, ylr, ycn = r16(n, zh, zw, cout), r16(2 * n, 3, zw, cout), r16(2 * n, zh, 3, cout), r16(4 * n, 3, 3, cout)
+    bias = rng.normal(0, 1, cout).astype(np.float32)
+    w_head = gu.bf16_round(rng.normal(0, 0.1, (cout, ncls)).astype(np.float32))
+    b_head = rng.normal(0, 1, ncls).astype(np.float32)
+    # the corrected zoom in float64
+    z = np.zeros((n, h, wd, cout))
+    for p in range(h):
+        for q in range(wd):
+            srcs = []
+            for i in range(p // 2, p // 2 + 1 + p % 2):
+                for j in range(q // 2, q // 2 + 1 + q % 2):
+                    rf = 1 if (p == 1 and i == 1) else 2 if (p == h - 2 and i == zh - 2) else 0
+                    cf = 1 if (q == 1 and j == 1) else 2 if (q == wd - 2 and j == zw - 2) else 0
+                    if not rf and not cf:
+                        srcs.append(y[:, i, j])
+                    elif not cf:
+                        srcs.append(ytb[(rf - 1) * n:rf * n, 1, j])
+                    elif not rf:
+                        srcs.append(ylr[(cf - 1) * n:cf * n, i, 1])
+                    else:
+                        k = (rf - 1) * 2 + (cf - 1)
+                        srcs.append(ycn[k * n:(k + 1) * n, 1, 1])
+            z[:, p, q] = np.mean(np.asarray(srcs, np.float64), axis=0)
+    conv = O.conv2d(x, w, 1, 1, 'SAME', np.float64) + bias + z
+    act = gu.bf16_round(O.relu(conv).astype(np.float32)).astype(np.float64)
+    ref = (act.reshape(-1, cout) @ w_head.astype(np.float64) + b_head).reshape(n, h, wd, ncls)
+    out = gu.conv2d_dual_head(x, w, None, None, bias, w_head, b_head, 1, (0, 0), (h, wd),
+                              zoom_residual=(y, ytb, ylr, ycn))
+    _close(out, ref, 2e-2, 'head conv with zoomed residual')
+    assert np.mean(np.abs(out - ref) > 5e-3) < 0.01
+
+
 def test_entry_points_reject_bad_arguments():
     """Every entry point validates its arguments on the host and returns a non-zero
     status with a message (no launch, no fault): null pointers, packed-weight dimensions
@@ -271,14 +314,17 @@ def test_entry_points_reject_bad_arguments():
                                          x.data_ptr(), 32, w.data_ptr(), b.data_ptr(), None, y.data_ptr(), None)
     # classifier-head form: bfloat16, at most 20 classes, a 16x16-MFMA configuration
     yh = torch.zeros((1, 8, 8, 20), dtype=torch.float32, device='cuda')
-    head = [x.data_ptr(), None, 0, w.data_ptr(), b.data_ptr(), None, w.data_ptr(), b.data_ptr(), 19,
-            yh.data_ptr(), 20, None]
+    head = [x.data_ptr(), None, 0, w.data_ptr(), b.data_ptr(), None, None, 0, 0, w.data_ptr(), b.data_ptr(),
+            19, yh.data_ptr(), 20, None]
     assert L.lib.fss_conv2d_dual_head_nhwc(ctypes.byref(good), *head) == 0
-    bad = list(head); bad[8] = 21
+    bad = list(head); bad[11] = 21
     assert 'cout_head' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
-    bad = list(head); bad[10] = 16
+    bad = list(head); bad[13] = 16
     assert 'y_head_ld' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
-    bad = list(head); bad[6] = None
+    zp = (ctypes.c_void_p * 4)(*[x.data_ptr()] * 4)
+    bad = list(head); bad[6] = zp; bad[7] = 4; bad[8] = 4          # 8x8 output is not 7x7
+    assert 'zoom_residual' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
+    bad = list(head); bad[9] = None
     assert 'null' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
     assert 'bf16' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(desc(in_dtype=L.F32, out_dtype=L.F32)),
                               *head)
