@@ -450,41 +450,40 @@ conv_igemm_kernel(const ConvArgs a) {
       for (int i = 0; i < MI; ++i) {
         f32x4 d0 = acc[i][2 * s], d1 = acc[i][2 * s + 1];
         if (a.zy != nullptr) {
-          // residual = corrected x2 zoom of zy at this lane's pixel: mean of 1, 2 or 4 sources
-          const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
-          if (m < a.M) {
-            const int f = m / HoWo, rem = m - f * HoWo;
-            const int p = rem / a.Wo, q = rem - p * a.Wo;
-            const int i0 = p >> 1, j0 = q >> 1, ni = 1 + (p & 1), nj = 1 + (q & 1);
-            float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+          // residual = corrected x2 zoom of zy at this lane's pixel: the mean of 1, 2 or 4
+          // sources, formed branch-free as a quarter of the sum over the 2 x 2 neighbourhood
+          // with the indices clamped (a source counted twice or four times), so that the 8
+          // loads are independent and in flight together
+          const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
+          const int f = m / HoWo, rem = m - f * HoWo;
+          const int p = rem / a.Wo, q = rem - p * a.Wo;
+          uint2 u0[4], u1[4];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-              const int da = nb >> 1, db = nb & 1;
-              if (da < ni && db < nj) {
-                const int zi = i0 + da, zj = j0 + db;
-                const int rf = (p == 1 && zi == 1) ? 1 : (p == a.Ho - 2 && zi == a.zH - 2) ? 2 : 0;
-                const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
-                const T* src;
-                if (rf == 0 && cf == 0)
-                  src = reinterpret_cast<const T*>(a.zy) + (((size_t)f * a.zH + zi) * a.zW + zj) * a.Cout;
-                else if (cf == 0)
-                  src = reinterpret_cast<const T*>(a.zytb) + ((((size_t)(rf - 1) * a.N + f) * 3 + 1) * a.zW + zj) * a.Cout;
-                else if (rf == 0)
-                  src = reinterpret_cast<const T*>(a.zylr) + ((((size_t)(cf - 1) * a.N + f) * a.zH + zi) * 3 + 1) * a.Cout;
-                else
-                  src = reinterpret_cast<const T*>(a.zycn) + (((size_t)((rf - 1) * 2 + (cf - 1)) * a.N + f) * 9 + 4) * a.Cout;
-                src += c0 + 4 * lg;
-                const uint2 u0 = *reinterpret_cast<const uint2*>(src), u1 = *reinterpret_cast<const uint2*>(src + 16);
-                r0[0] += __uint_as_float(u0.x << 16); r0[1] += __uint_as_float(u0.x & 0xffff0000u);
-                r0[2] += __uint_as_float(u0.y << 16); r0[3] += __uint_as_float(u0.y & 0xffff0000u);
-                r1[0] += __uint_as_float(u1.x << 16); r1[1] += __uint_as_float(u1.x & 0xffff0000u);
-                r1[2] += __uint_as_float(u1.y << 16); r1[3] += __uint_as_float(u1.y & 0xffff0000u);
-              }
-            }
-            const float sc = 1.0f / (float)(ni * nj);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * sc; d1[e] += r1[e] * sc; }
+          for (int nb = 0; nb < 4; ++nb) {
+            const int zi = (p >> 1) + ((nb >> 1) & p), zj = (q >> 1) + (nb & q & 1);
+            const int rf = (p == 1 && zi == 1) ? 1 : (p == a.Ho - 2 && zi == a.zH - 2) ? 2 : 0;
+            const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
+            const T* src = reinterpret_cast<const T*>(a.zy) + (((size_t)f * a.zH + zi) * a.zW + zj) * a.Cout;
+            if (rf != 0 && cf == 0)
+              src = reinterpret_cast<const T*>(a.zytb) + ((((size_t)(rf - 1) * a.N + f) * 3 + 1) * a.zW + zj) * a.Cout;
+            if (rf == 0 && cf != 0)
+              src = reinterpret_cast<const T*>(a.zylr) + ((((size_t)(cf - 1) * a.N + f) * a.zH + zi) * 3 + 1) * a.Cout;
+            if (rf != 0 && cf != 0)
+              src = reinterpret_cast<const T*>(a.zycn) + (((size_t)((rf - 1) * 2 + (cf - 1)) * a.N + f) * 9 + 4) * a.Cout;
+            src += c0 + 4 * lg;
+            u0[nb] = *reinterpret_cast<const uint2*>(src);
+            u1[nb] = *reinterpret_cast<const uint2*>(src + 16);
           }
+          float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            r0[0] += __uint_as_float(u0[nb].x << 16); r0[1] += __uint_as_float(u0[nb].x & 0xffff0000u);
+            r0[2] += __uint_as_float(u0[nb].y << 16); r0[3] += __uint_as_float(u0[nb].y & 0xffff0000u);
+            r1[0] += __uint_as_float(u1[nb].x << 16); r1[1] += __uint_as_float(u1[nb].x & 0xffff0000u);
+            r1[2] += __uint_as_float(u1[nb].y << 16); r1[3] += __uint_as_float(u1[nb].y & 0xffff0000u);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.25f; d1[e] += r1[e] * 0.25f; }
         } else if (a.res != nullptr) {
           const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
           if (m < a.M) {
@@ -723,8 +722,10 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   X(29, 128, 128, 2, 4, 128, 2, 16) \
   X(30, 128, 128, 4, 2, 128, 2, 16) \
   X(31, 128, 128, 2, 4, 64, 3, 16)  \
-  X(32, 128, 64, 4, 2, 128, 2, 16)
-static constexpr int kNumConvConfigs = 32;
+  X(32, 128, 64, 4, 2, 128, 2, 16)  \
+  X(33, 128, 256, 2, 4, 64, 2, 16)  \
+  X(34, 128, 256, 2, 4, 64, 3, 16)
+static constexpr int kNumConvConfigs = 34;
 
 // automatic choice when the caller does not name a configuration
 static int default_config(const ConvArgs& a) {
