@@ -74,7 +74,9 @@ def test_forward_parity(case, dtype):
     rng = np.random.default_rng(0)
     img = rng.integers(0, 256, in_shape).astype(np.uint8)
     ref = oracle_logits(arch, ext, fs, pf, img, pad_shape, weights)
-    cg = plan.CompiledGraph(g, outs, weights, dtype=dtype)
+    # commute_zoom=True: the plan large batches get (fusion convs in front of their zoom); the
+    # small-batch plan is compared with it in test_layer_fusions_agree_with_the_unfused_plan
+    cg = plan.CompiledGraph(g, outs, weights, dtype=dtype, commute_zoom=True)
     logits, labels, colors = cg.run(img)
     assert logits.shape == ref.shape
     scale = float(np.abs(ref).max())
