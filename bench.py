@@ -165,6 +165,7 @@ def main():
         prof = cg.profile(repeats=3)
         conv_ms = sum(p['ms'] for p in prof if p['kind'] == 'conv')
         conv_flops = sum(p['flops'] for p in prof if p['kind'] == 'conv')
+        graph_flops = sum(p['graph_flops'] for p in prof if p['kind'] == 'conv')
         n_conv = sum(1 for p in prof if p['kind'] == 'conv')
         total_ms = sum(p['ms'] for p in prof)
         other_bytes = sum(p['bytes'] for p in prof if p['kind'] != 'conv')
@@ -195,7 +196,11 @@ def main():
                          'algorithmic_bytes': sum(p['bytes'] for p in prof if p['kind'] == 'conv') / n_conv,
                          'launches_per_step': n_conv,
                          'avg_launch_ms': conv_ms / n_conv,
-                         'algorithmic_gflop_per_frame': conv_flops / B / 1e9},
+                         'algorithmic_gflop_per_frame': conv_flops / B / 1e9,
+                         # the same launches priced with the FLOP of the graph as written (the
+                         # fusion convolutions run on a quarter of the pixels after a rewrite)
+                         'graph_gflop_per_frame': graph_flops / B / 1e9,
+                         'graph_tflops': graph_flops / (conv_ms * 1e-3) / 1e12},
             'hbm_kernels': {'ms_per_step': other_ms,
                             'achieved_gbps': other_bytes / (other_ms * 1e-3) / 1e9 if other_ms > 0 else None,
                             'peak_gbps': 8000.0},

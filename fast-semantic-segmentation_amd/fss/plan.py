@@ -78,11 +78,15 @@ class Val(object):
 
 
 class Step(object):
-    __slots__ = ('kind', 'name', 'fn', 'args', 'flops', 'bytes', 'keep', 'stream', 'waits', 'signal')
+    __slots__ = ('kind', 'name', 'fn', 'args', 'flops', 'graph_flops', 'bytes', 'keep', 'stream', 'waits',
+                 'signal')
 
-    def __init__(self, kind, name, fn, args, flops=0, nbytes=0, keep=None):
+    def __init__(self, kind, name, fn, args, flops=0, nbytes=0, keep=None, graph_flops=None):
         self.kind, self.name, self.fn, self.args = kind, name, fn, args   # args[-1] is the stream
         self.flops, self.bytes, self.keep = flops, nbytes, keep
+        # FLOP of the graph nodes this launch stands for, as the graph is written (differs from
+        # `flops`, the FLOP executed, where a rewrite lowered the operation count)
+        self.graph_flops = flops if graph_flops is None else graph_flops
         self.stream = 0         # 0: the plan's stream, 1: the side stream
         self.waits = []         # events its stream waits for before the launch
         self.signal = None      # event recorded on its stream after the launch
@@ -244,8 +248,8 @@ class CompiledGraph(object):
             return None
         return ln.consumers[0]
 
-    def _emit(self, kind, name, fname, args, flops=0, nbytes=0, keep=None):
-        st = Step(kind, name, getattr(lib, fname), args, flops, nbytes, keep)
+    def _emit(self, kind, name, fname, args, flops=0, nbytes=0, keep=None, graph_flops=None):
+        st = Step(kind, name, getattr(lib, fname), args, flops, nbytes, keep, graph_flops)
         self.steps.append(st)
         self.step_fname.append(fname)
 
@@ -474,7 +478,7 @@ class CompiledGraph(object):
             return None
         return c
 
-    def _emit_head(self, head, d, x, x2, cin2, wdev, bdev, cout, k, name, res=None, zres=None):
+    def _emit_head(self, head, d, x, x2, cin2, wdev, bdev, cout, k, name, res=None, zres=None, graph_k=None):
         """Emits conv (+ second input) + classifier `head` as one launch; the activated
         cout-channel tensor gets no buffer."""
         n, ho, wo, ncls = head.shape
@@ -501,7 +505,8 @@ class CompiledGraph(object):
                     bdev.data_ptr(), res.ptr if res is not None else None, zptrs,
                     zres[0].shape[1] if zres else 0, zres[0].shape[2] if zres else 0, whdev.data_ptr(),
                     bhdev.data_ptr(), ncls, out.ptr, out.ld, self.sh),
-                   flops=2 * n * ho * wo * cout * (k + ncls), nbytes=nbytes, keep=(d, zptrs))
+                   flops=2 * n * ho * wo * cout * (k + ncls), nbytes=nbytes, keep=(d, zptrs),
+                   graph_flops=2 * n * ho * wo * cout * ((graph_k or k) + ncls))
 
     def _zoom_source(self, B):
         """The low-resolution node x when conv B is conv3x3, dilation 2, stride 1, SAME of a
@@ -580,7 +585,7 @@ class CompiledGraph(object):
             self._emit('conv', base + tag, 'fss_conv2d_nhwc',
                        (ctypes.byref(d), v.ptr, wB.data_ptr(), None, None, y.ptr, self.sh),
                        flops=2 * nn * hh * ww * cout * 9 * cin,
-                       nbytes=(nn * hh * ww * (cin + cout) + cout * 9 * cin) * esz, keep=d)
+                       nbytes=(nn * hh * ww * (cin + cout) + cout * 9 * cin) * esz, keep=d, graph_flops=0)
             ys.append(y)
         self.temps.extend([tb, lr, cn] + ys)        # buffers no graph node owns
         head = self._head_partner(result, cout, dt) if cin2 % 64 == 0 else None
@@ -603,7 +608,7 @@ class CompiledGraph(object):
         if head is not None:
             # the classifier launch interpolates the source-resolution results itself
             return self._emit_head(head, d, x2, None, 0, wA, bdev, cout, cin2, name, res=r,
-                                   zres=None if r is not None else ys)
+                                   zres=None if r is not None else ys, graph_k=9 * cin + cin2)
         out = Val(self._alloc(B.shape, dt), B.shape, dt)
         for node in (A, B, add, result):
             self.vals[node] = out
@@ -611,7 +616,8 @@ class CompiledGraph(object):
         self._emit('conv', name, 'fss_conv2d_nhwc',
                    (ctypes.byref(d), x2.ptr, wA.data_ptr(), bdev.data_ptr(), r.ptr, out.ptr, self.sh),
                    flops=2 * n * ho * wo * cout * cin2,
-                   nbytes=(n * ho * wo * (cin2 + 2 * cout) + cout * cin2) * esz, keep=d)
+                   nbytes=(n * ho * wo * (cin2 + 2 * cout) + cout * cin2) * esz, keep=d,
+                   graph_flops=2 * n * ho * wo * cout * (9 * cin + cin2))
 
     def _l_conv_dual(self, A, B):
         """relu?(conv B + conv1x1 A) in one launch; A is the node being lowered."""
@@ -1362,7 +1368,7 @@ class CompiledGraph(object):
                 best[k] = min(best[k], ms.value)
         for e in evs:
             _lib.call('fss_event_destroy', e)
-        return [dict(kind=s.kind, name=s.name, ms=best[k], flops=s.flops, bytes=s.bytes,
+        return [dict(kind=s.kind, name=s.name, ms=best[k], flops=s.flops, graph_flops=s.graph_flops, bytes=s.bytes,
                      config=((s.keep[0] if isinstance(s.keep, tuple) else s.keep).config
                              if s.kind == 'conv' else None))
                 for k, s in enumerate(self.steps)]
