@@ -465,11 +465,11 @@ conv_igemm_kernel(const ConvArgs a) {
             const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
             const T* src = reinterpret_cast<const T*>(a.zy) + (((size_t)f * a.zH + zi) * a.zW + zj) * a.Cout;
             if (rf != 0 && cf == 0)
-              src = reinterpret_cast<const T*>(a.zytb) + ((((size_t)(rf - 1) * a.N + f) * 3 + 1) * a.zW + zj) * a.Cout;
+              src = reinterpret_cast<const T*>(a.zytb) + (((size_t)(rf - 1) * a.N + f) * a.zW + zj) * a.Cout;
             if (rf == 0 && cf != 0)
-              src = reinterpret_cast<const T*>(a.zylr) + ((((size_t)(cf - 1) * a.N + f) * a.zH + zi) * 3 + 1) * a.Cout;
+              src = reinterpret_cast<const T*>(a.zylr) + (((size_t)(cf - 1) * a.N + f) * a.zH + zi) * a.Cout;
             if (rf != 0 && cf != 0)
-              src = reinterpret_cast<const T*>(a.zycn) + (((size_t)((rf - 1) * 2 + (cf - 1)) * a.N + f) * 9 + 4) * a.Cout;
+              src = reinterpret_cast<const T*>(a.zycn) + ((size_t)((rf - 1) * 2 + (cf - 1)) * a.N + f) * a.Cout;
             src += c0 + 4 * lg;
             u0[nb] = *reinterpret_cast<const uint2*>(src);
             u1[nb] = *reinterpret_cast<const uint2*>(src + 16);

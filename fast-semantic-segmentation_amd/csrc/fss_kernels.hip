@@ -328,8 +328,8 @@ __global__ void zoom2_border_gather_kernel(const T* __restrict__ x, T* __restric
 }
 
 // r[2H-1][2W-1] = the x2 zoom of y[H][W] with the border results substituted as described
-// above (ytb / ylr / ycn = the convolutions of tb / lr / cn; their middle row / column /
-// pixel is used).
+// above (ytb [2n][W], ylr [2n][H], ycn [4n] = the middle row / column / pixel of the
+// convolutions of tb / lr / cn: the caller convolves them without padding across the 3).
 template <typename T>
 __global__ void zoom2_conv_commute_kernel(const T* __restrict__ y, const T* __restrict__ ytb,
                                           const T* __restrict__ ylr, const T* __restrict__ ycn,
@@ -355,9 +355,9 @@ __global__ void zoom2_conv_commute_kernel(const T* __restrict__ y, const T* __re
       const int cf = (q == 1 && j == 1) ? 1 : (q == Wo - 2 && j == W - 2) ? 2 : 0;   // 1 left, 2 right
       const T* src;
       if (rf == 0 && cf == 0) src = y + (((size_t)f * H + i) * W + j) * C;
-      else if (cf == 0) src = ytb + ((((size_t)(rf - 1) * N + f) * 3 + 1) * W + j) * C;
-      else if (rf == 0) src = ylr + ((((size_t)(cf - 1) * N + f) * H + i) * 3 + 1) * C;
-      else src = ycn + (((size_t)((rf - 1) * 2 + (cf - 1)) * N + f) * 9 + 4) * C;
+      else if (cf == 0) src = ytb + (((size_t)(rf - 1) * N + f) * W + j) * C;
+      else if (rf == 0) src = ylr + (((size_t)(cf - 1) * N + f) * H + i) * C;
+      else src = ycn + ((size_t)((rf - 1) * 2 + (cf - 1)) * N + f) * C;
       Chunk<T> v;
       v.load(src + (size_t)ch * E);
 #pragma unroll

@@ -575,17 +575,22 @@ class CompiledGraph(object):
                    (xl.ptr, tb.ptr, lr.ptr, cn.ptr, n, h, w, cin, _CODE[dt], self.sh),
                    nbytes=2 * crop_px * cin * esz)
         ys = []
-        for tag, v in (('@source', xl), ('@rows', tb), ('@columns', lr), ('@corners', cn)):
+        # the crops are convolved without padding across their 3 rows / columns: only the
+        # middle row / column / pixel comes out
+        for tag, v, pt, pl in (('@source', xl, 1, 1), ('@rows', tb, 0, 1), ('@columns', lr, 1, 0),
+                               ('@corners', cn, 0, 0)):
             nn, hh, ww, _ = v.shape
-            y = Val(self._alloc((nn, hh, ww, cout), dt), (nn, hh, ww, cout), dt)
+            oh, ow = (hh if pt else 1), (ww if pl else 1)
+            y = Val(self._alloc((nn, oh, ow, cout), dt), (nn, oh, ow, cout), dt)
             d = _lib.ConvDesc(n=nn, h=hh, w=ww, cin=cin, cout=cout, kh=3, kw=3, stride=1, dilation=1,
-                              pad_top=1, pad_left=1, ho=hh, wo=ww, act=_lib.ACT_CODES[None],
+                              pad_top=pt, pad_left=pl, ho=oh, wo=ow, act=_lib.ACT_CODES[None],
                               in_dtype=_CODE[dt], out_dtype=_CODE[dt], y_ld=y.ld, res_ld=0,
                               k_pad=k_pad, cout_pad=cout_pad)
             self._emit('conv', base + tag, 'fss_conv2d_nhwc',
                        (ctypes.byref(d), v.ptr, wB.data_ptr(), None, None, y.ptr, self.sh),
-                       flops=2 * nn * hh * ww * cout * 9 * cin,
-                       nbytes=(nn * hh * ww * (cin + cout) + cout * 9 * cin) * esz, keep=d, graph_flops=0)
+                       flops=2 * nn * oh * ow * cout * 9 * cin,
+                       nbytes=(nn * hh * ww * cin + nn * oh * ow * cout + cout * 9 * cin) * esz, keep=d,
+                       graph_flops=0)
             ys.append(y)
         self.temps.extend([tb, lr, cn] + ys)        # buffers no graph node owns
         head = self._head_partner(result, cout, dt) if cin2 % 64 == 0 else None

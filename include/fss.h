@@ -139,7 +139,8 @@ int fss_conv2d_dual_nhwc(const fss_conv_desc* desc, const void* x, const void* x
  * desc->config: 0 or a 16x16-MFMA configuration whose block columns >= cout;
  * `residual`: bf16 [pixels][cout] with pixel stride desc->res_ld, or NULL.
  * `zoom_residual` (or NULL): the residual given at half resolution, as the four tensors
- * {y, ytb, ylr, ycn} of fss_zoom2_conv_commute (bf16, cout channels, y: [n,zh,zw,cout]) and
+ * {y, ytb, ylr, ycn} of fss_zoom2_conv_commute (bf16, cout channels, y: [n,zh,zw,cout],
+ * ytb: [2n,1,zw,cout], ylr: [2n,zh,1,cout], ycn: [4n,1,1,cout]) and
  * interpolated in the epilogue instead of being read from a zoomed copy; ho = 2 zh - 1,
  * wo = 2 zw - 1.
  * desc->out_dtype and y_ld are ignored.  Equals fss_conv2d_dual_nhwc followed by
@@ -160,9 +161,12 @@ int fss_conv2d_dual_head_nhwc(const fss_conv_desc* desc, const void* x, const vo
  *   fss_zoom2_border_gather: crops of x [n,h,w,c] with that row / column zeroed:
  *     tb [2n,3,w,c] (top rows 0-2 with row 0 zero; bottom rows h-3..h-1 with the last zero),
  *     lr [2n,h,3,c] (left, right likewise), cn [4n,3,3,c] (corners TL, TR, BL, BR, both zero).
- *   The caller convolves x, tb, lr, cn with the same 3x3 filter (dilation 1, padding 1).
- *   fss_zoom2_conv_commute: r [n,2h-1,2w-1,c] = zoom_x2(y) with the middle row / column /
- *     pixel of ytb / ylr / ycn substituted where the identity needs them.  h, w >= 4. */
+ *   The caller convolves x with the 3x3 filter (dilation 1, padding 1) -> y [n,h,w,c'] and
+ *   the crops with the same filter, padded along their long axis only, so that just the
+ *   middle row / column / pixel comes out: ytb [2n,1,w,c'] (pad_top 0, pad_left 1),
+ *   ylr [2n,h,1,c'] (pad_top 1, pad_left 0), ycn [4n,1,1,c'] (no padding).
+ *   fss_zoom2_conv_commute: r [n,2h-1,2w-1,c'] = zoom_x2(y) with ytb / ylr / ycn substituted
+ *     where the identity needs them.  h, w >= 4. */
 int fss_zoom2_border_gather(const void* x, void* tb, void* lr, void* cn, int n, int h, int w, int c,
                             int dtype, void* stream);
 int fss_zoom2_conv_commute(const void* y, const void* ytb, const void* ylr, const void* ycn, void* r,

@@ -150,7 +150,8 @@ def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), ou
 def zoomed_dilated_conv(x, w, dt='f32'):
     """conv3x3 with dilation 2 (SAME) of the align_corners x2 zoom of x, computed at the source
     resolution: fss_zoom2_border_gather, four fss_conv2d_nhwc launches (x and the three crop
-    tensors, same filter, dilation 1), fss_zoom2_conv_commute.  Returns float32
+    tensors, same filter, dilation 1, the crops unpadded across their 3 rows / columns),
+    fss_zoom2_conv_commute.  Returns float32
     [n,2h-1,2w-1,cout]."""
     n, h, wd, cin = x.shape
     cout = w.shape[3]
@@ -162,11 +163,12 @@ def zoomed_dilated_conv(x, w, dt='f32'):
     _lib.call('fss_zoom2_border_gather', xd.data_ptr(), tb.data_ptr(), lr.data_ptr(), cn.data_ptr(),
               n, h, wd, cin, code, None)
     outs = []
-    for t in (xd, tb, lr, cn):
+    for t, pt, pl in ((xd, 1, 1), (tb, 0, 1), (lr, 1, 0), (cn, 0, 0)):
         nn, hh, ww, _ = t.shape
-        y = mk(nn, hh, ww, cout)
+        oh, ow = (hh if pt else 1), (ww if pl else 1)
+        y = mk(nn, oh, ow, cout)
         d = _lib.ConvDesc(n=nn, h=hh, w=ww, cin=cin, cout=cout, kh=3, kw=3, stride=1, dilation=1,
-                          pad_top=1, pad_left=1, ho=hh, wo=ww, act=_lib.ACT_CODES[None], in_dtype=code,
+                          pad_top=pt, pad_left=pl, ho=oh, wo=ow, act=_lib.ACT_CODES[None], in_dtype=code,
                           out_dtype=code, y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad, config=0)
         _lib.call('fss_conv2d_nhwc', ctypes.byref(d), t.data_ptr(), wdev.data_ptr(), None, None,
                   y.data_ptr(), None)

@@ -239,7 +239,7 @@ def test_head_conv_interpolates_its_residual_from_the_source_resolution():
     h, wd = 2 * zh - 1, 2 * zw - 1
     r16 = lambda *shape: gu.bf16_round(rng.normal(0, 1, shape).astype(np.float32))
     x, w = r16(n, h, wd, cin), gu.bf16_round(rng.normal(0, 0.1, (1, 1, cin, cout)).astype(np.float32))
-    y, ytb, ylr, ycn = r16(n, zh, zw, cout), r16(2 * n, 3, zw, cout), r16(2 * n, zh, 3, cout), r16(4 * n, 3, 3, cout)
+    y, ytb, ylr, ycn = r16(n, zh, zw, cout), r16(2 * n, 1, zw, cout), r16(2 * n, zh, 1, cout), r16(4 * n, 1, 1, cout)
     bias = rng.normal(0, 1, cout).astype(np.float32)
     w_head = gu.bf16_round(rng.normal(0, 0.1, (cout, ncls)).astype(np.float32))
     b_head = rng.normal(0, 1, ncls).astype(np.float32)
@@ -255,12 +255,12 @@ def test_head_conv_interpolates_its_residual_from_the_source_resolution():
                     if not rf and not cf:
                         srcs.append(y[:, i, j])
                     elif not cf:
-                        srcs.append(ytb[(rf - 1) * n:rf * n, 1, j])
+                        srcs.append(ytb[(rf - 1) * n:rf * n, 0, j])
                     elif not rf:
-                        srcs.append(ylr[(cf - 1) * n:cf * n, i, 1])
+                        srcs.append(ylr[(cf - 1) * n:cf * n, i, 0])
                     else:
                         k = (rf - 1) * 2 + (cf - 1)
-                        srcs.append(ycn[k * n:(k + 1) * n, 1, 1])
+                        srcs.append(ycn[k * n:(k + 1) * n, 0, 0])
             z[:, p, q] = np.mean(np.asarray(srcs, np.float64), axis=0)
     conv = O.conv2d(x, w, 1, 1, 'SAME', np.float64) + bias + z
     act = gu.bf16_round(O.relu(conv).astype(np.float32)).astype(np.float64)
