@@ -11,6 +11,9 @@
 namespace fss {
 
 void set_error(const std::string& msg);
+// Resolves, for the current device, the device address of the static scratch array behind
+// fss_avgpool_pyramid_nhwc_static (defined next to the array, called by fss_set_device).
+int pyramid_scratch_init();
 
 #define FSS_CHECK_HIP(expr)                                                    \
   do {                                                                         \

@@ -5,6 +5,7 @@
 // consecutive bytes whenever a pixel has >= 64 chunks, and whole pixels
 // otherwise.  Arithmetic is float regardless of the storage dtype.
 #include <algorithm>
+#include <mutex>
 
 #include "fss_common.h"
 
@@ -1048,10 +1049,12 @@ int fss_avgpool_bins_nhwc(const void* x, void* y, int n, int h, int wd, int c, i
   return 0;
 }
 
-int fss_avgpool_pyramid_nhwc(const void* x, void* const* y, const int* kh, const int* kw,
-                             const int* bh, const int* bw, int levels, float* workspace,
-                             size_t workspace_bytes, int n, int h, int wd, int c, int dtype,
-                             void* stream) {
+// Both launches of the one-pass pyramid pooling; `workspace` (device memory, checked against
+// workspace_bytes) carries the row sums from the first launch to the second.
+static int pyramid_pool_launch(const void* x, void* const* y, const int* kh, const int* kw,
+                               const int* bh, const int* bw, int levels, float* workspace,
+                               size_t workspace_bytes, const char* too_small, int n, int h, int wd,
+                               int c, int dtype, void* stream) {
   FSS_REQUIRE(x && y && kh && kw && bh && bw && workspace, "null argument");
   FSS_DTYPE_OK(dtype);
   FSS_CHUNK_OK(c, dtype);
@@ -1082,8 +1085,7 @@ int fss_avgpool_pyramid_nhwc(const void* x, void* const* y, const int* kh, const
     a.total_bins += bh[l] * bw[l];
     a.y[l] = y[l];
   }
-  FSS_REQUIRE(workspace_bytes >= (size_t)n * h * a.total_cols * c * sizeof(float),
-              "workspace smaller than n*h*sum(bw)*c floats");
+  FSS_REQUIRE(workspace_bytes >= (size_t)n * h * a.total_cols * c * sizeof(float), too_small);
   const int cc = c / (dtype == FSS_F32 ? 4 : 8);
   hipStream_t s = (hipStream_t)stream;
   const size_t t1 = (size_t)n * h * cc, t2 = (size_t)n * a.total_bins * cc;
@@ -1135,6 +1137,58 @@ int fss_avgpool_pyramid_nhwc(const void* x, void* const* y, const int* kh, const
   }
   FSS_LAUNCH_CHECK();
   return 0;
+}
+
+int fss_avgpool_pyramid_nhwc(const void* x, void* const* y, const int* kh, const int* kw,
+                             const int* bh, const int* bw, int levels, float* workspace,
+                             size_t workspace_bytes, int n, int h, int wd, int c, int dtype,
+                             void* stream) {
+  return pyramid_pool_launch(x, y, kh, kw, bh, bw, levels, workspace, workspace_bytes,
+                             "workspace smaller than n*h*sum(bw)*c floats", n, h, wd, c, dtype, stream);
+}
+
+// Row-sum scratch of fss_avgpool_pyramid_nhwc_static: one array per GPU the library runs on,
+// held until the process ends.  Host code never uses the array's name as an address (it is a
+// host-side stand-in); the device address is resolved once per device and kept below.
+constexpr size_t kPyrScratchBytes = (size_t)FSS_PYRAMID_STATIC_MAX_BYTES;
+static __device__ __align__(256) float scratch[kPyrScratchBytes / sizeof(float)];
+constexpr int kMaxDevices = 64;
+static float* g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mutex;
+
+// Device address of `scratch` on the current device (resolved on the first call per device).
+static int pyramid_scratch(float** out) {
+  int dev = -1;
+  FSS_CHECK_HIP(hipGetDevice(&dev));
+  FSS_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index beyond the scratch table");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    FSS_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    FSS_REQUIRE(p != nullptr, "no device address for the scratch array");
+    g_scratch_ptr[dev] = static_cast<float*>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+
+// Set-up hook of fss_set_device: resolves the address for the device just made current, so
+// that the entry point's own first call on it has nothing left to look up.
+extern "C++" int fss::pyramid_scratch_init() {
+  float* p = nullptr;
+  return pyramid_scratch(&p);
+}
+
+int fss_avgpool_pyramid_nhwc_static(const void* x, void* const* y, const int* kh, const int* kw,
+                                    const int* bh, const int* bw, int levels, int n, int h, int wd,
+                                    int c, int dtype, void* stream) {
+  float* ws = nullptr;
+  const int rc = pyramid_scratch(&ws);
+  if (rc) return rc;
+  // every row sum the second launch reads is written by the first, so nothing is cleared
+  return pyramid_pool_launch(x, y, kh, kw, bh, bw, levels, ws, kPyrScratchBytes,
+                             "n*h*sum(bw)*c floats exceed FSS_PYRAMID_STATIC_MAX_BYTES", n, h, wd, c,
+                             dtype, stream);
 }
 
 int fss_resize_bilinear_nhwc(const void* x, void* y, int n, int h, int wd, int c, int ho, int wo,

@@ -23,7 +23,7 @@ int fss_device_count(int* count) {
 
 int fss_set_device(int device) {
   FSS_CHECK_HIP(hipSetDevice(device));
-  return 0;
+  return fss::pyramid_scratch_init();
 }
 
 int fss_device_name(char* buf, int buflen) {

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FSS_LIB') or os.path.join(os.path.dirname(_HERE), 'libfss_gfx950.so')
 
 F32, BF16 = 0, 1
+PYRAMID_STATIC_MAX_BYTES = 32 << 20     # FSS_PYRAMID_STATIC_MAX_BYTES
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 ACT_CODES = {None: ACT_NONE, 'relu': ACT_RELU, 'relu6': ACT_RELU6}
 
@@ -75,6 +76,8 @@ PROTOTYPES = {
     'fss_resize_bilinear_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     'fss_avgpool_pyramid_nhwc': (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_int_p, c_int_p, c_int_p, c_int_p,
                                          c_int, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    'fss_avgpool_pyramid_nhwc_static': (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_int_p, c_int_p, c_int_p,
+                                                c_int_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'fss_pyramid_add_nhwc': (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_int_p, c_int_p,
                                      c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'fss_add_act': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),

@@ -212,6 +212,20 @@ int fss_avgpool_pyramid_nhwc(const void* x, void* const* y, const int* kh, const
                              size_t workspace_bytes, int n, int h, int wd, int c, int dtype,
                              void* stream);
 
+/* fss_avgpool_pyramid_nhwc without a workspace argument, for callers that cannot allocate
+ * device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  It has no counterpart in the reference.  The row sums go to a static device
+ * array of FSS_PYRAMID_STATIC_MAX_BYTES inside the library (every GPU the library runs on
+ * holds one copy until the process ends); n*h*sum(bw)*c*4 bytes beyond that are rejected
+ * with an error.  The call allocates and frees nothing; its first call on a device (or
+ * fss_set_device) looks the array's device address up once.  Every call on one GPU uses
+ * that GPU's array, so two calls that overlap on one GPU (different streams) race; calls
+ * ordered on one stream are safe.  Results are bit-identical to fss_avgpool_pyramid_nhwc. */
+#define FSS_PYRAMID_STATIC_MAX_BYTES (32u << 20)
+int fss_avgpool_pyramid_nhwc_static(const void* x, void* const* y, const int* kh, const int* kw,
+                                    const int* bh, const int* bw, int levels, int n, int h,
+                                    int wd, int c, int dtype, void* stream);
+
 /* tf.image.resize_bilinear (TF 1.x legacy sampling), optional align_corners.
  * Replaces architectures/icnet_architecture.py:249,264-266,
  * architectures/pspnet_architecture.py:136-139,158-160,
