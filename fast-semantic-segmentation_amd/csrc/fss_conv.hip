@@ -128,8 +128,9 @@ template <> struct Mma<float, 16> {
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to the
 // 1 KiB of LDS starting at the wave-uniform byte address `lds_dst`.  M0 (the DMA's
-// LDS base) is written and consumed inside the one statement; nothing else in
-// this translation unit reads M0.
+// LDS base) is written and consumed inside the one statement and declared clobbered,
+// so the compiler never keeps a value of its own (s_movrel / gpr-index setup) in it
+// across the statement.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   asm volatile(
       "s_mov_b32 m0, %1\n\t"
@@ -137,7 +138,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
       "global_load_lds_dwordx4 %0, off"
       :
       : "v"(gsrc), "s"(lds_dst)
-      : "memory");
+      : "memory", "m0");
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {

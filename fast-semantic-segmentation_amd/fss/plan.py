@@ -98,7 +98,7 @@ _OUT_ARGS = {
     'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,), 'fss_conv2d_dual_nhwc': (7,),
     'fss_conv2d_dual_head_nhwc': (13,), 'fss_zoom2_border_gather': (1, 2, 3), 'fss_zoom2_conv_commute': (4,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
-    'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1,), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
+    'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1, 7), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
     'fss_add_act': (2,), 'fss_copy_channels': (2,), 'fss_upsample_argmax': (1, 2),
     'fss_label_lut': (1,),
 }
@@ -129,6 +129,7 @@ class CompiledGraph(object):
         self.lazy = {}          # LNode -> (tag, info..., materialise closure)
         self.keepalive = []     # device-side constants (packed weights, biases, tables)
         self.temps = []         # activation buffers between launches that stand for one graph node
+        self.workspaces = []    # scratch tensors a launch both writes and reads
         self.input_val = None
         self.graph_exec = None
         self.param_bytes = 0
@@ -148,12 +149,13 @@ class CompiledGraph(object):
         self.dual = {}          # 1x1 conv node -> the conv whose output it is added to (one launch)
         self.two_streams = False
         self.release_after = None
+        self.stream_choice = 'single: not requested'
         self.events = []
-        self.retired_graphs = []
         self.tuned_now = 0      # layer shapes timed by this plan (0: all came from the table)
         with torch.cuda.device(self.device):
             self._import(graph, outputs, commute_classifier)
             self._lower()
+            self._dependencies()                  # every pointer of every launch must resolve
             torch.cuda.synchronize(self.device)   # constants were uploaded on torch's stream
             if autotune:
                 self._autotune_convs()
@@ -835,7 +837,7 @@ class CompiledGraph(object):
             bw = (ctypes.c_int * L)(*[s_.shape[2] for s_ in sibs])
             cols = sum(s_.shape[2] for s_ in sibs)
             work = torch.empty((n * h * cols * c,), dtype=torch.float32, device=self.device)
-            self.keepalive.append(work)
+            self.workspaces.append(work)
             self._emit('avgpool', 'avg_pool_pyramid', 'fss_avgpool_pyramid_nhwc',
                        (x.ptr, ptrs, kh, kw, bh, bw, L, work.data_ptr(), work.numel() * 4, n, h, w, c,
                         _CODE[x.dt], self.sh),
@@ -1120,37 +1122,48 @@ class CompiledGraph(object):
 
     # ------------------------------------------------------------ two streams
     def _dependencies(self):
-        """deps[i] = steps that must finish before step i starts, found from the
-        activation buffers each launch reads and writes (pointer arguments that fall
-        inside a buffer of the plan; _OUT_ARGS says which of them are written)."""
-        ranges, seen = [], set()
-        for v in list(self.vals.values()) + self.temps + [self.input_val]:
-            t = v.buf
-            if t.data_ptr() not in seen:
-                seen.add(t.data_ptr())
-                ranges.append((t.data_ptr(), t.data_ptr() + t.numel() * t.element_size()))
-        ranges.sort()
-        starts = [r[0] for r in ranges]
+        """deps[i] = steps that must finish before step i starts, found from the buffers each
+        launch reads and writes.  Pointer arguments are recognised by the entry point's
+        prototype; _OUT_ARGS says which of them are written.  Every pointer must fall inside
+        a buffer the plan knows - an activation (vals / temps / input), a workspace, or a
+        constant uploaded at compile time (weights, biases, tables: read-only, no edges) -
+        otherwise the schedule could miss an edge, and the plan build fails."""
+        def spans(tensors):
+            out, seen = [], set()
+            for t in tensors:
+                if t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    out.append((t.data_ptr(), t.data_ptr() + max(t.numel() * t.element_size(), 1)))
+            out.sort()
+            return out, [r[0] for r in out]
 
-        def buf_of(ptr):
-            k = bisect.bisect_right(starts, ptr) - 1
-            return k if k >= 0 and ptr < ranges[k][1] else None
+        ranges, starts = spans([v.buf for v in list(self.vals.values()) + self.temps + [self.input_val]]
+                               + self.workspaces)
+        consts, cstarts = spans(self.keepalive)
+
+        def find(table, first, ptr):
+            k = bisect.bisect_right(first, ptr) - 1
+            return k if k >= 0 and ptr < table[k][1] else None
 
         last_writer, readers, deps, main_src = {}, {}, [], []
         for i, (s, fname) in enumerate(zip(self.steps, self.step_fname)):
             outs = _OUT_ARGS[fname]
+            argtypes = _lib.PROTOTYPES[fname][1]
             rd, wr = [], []
             for ai, arg in enumerate(s.args[:-1]):
-                if isinstance(arg, int):
-                    ptrs = [arg]
-                elif isinstance(arg, ctypes.Array) and getattr(arg, '_type_', None) is ctypes.c_void_p:
+                if isinstance(arg, ctypes.Array) and getattr(arg, '_type_', None) is ctypes.c_void_p:
                     ptrs = [q for q in arg if q]
+                elif argtypes[ai] is ctypes.c_void_p and isinstance(arg, int) and arg:
+                    ptrs = [arg]
                 else:
                     continue
                 for q in ptrs:
-                    b = buf_of(q)
+                    b = find(ranges, starts, q)
                     if b is not None:
                         (wr if ai in outs else rd).append(b)
+                    elif find(consts, cstarts, q) is None or ai in outs:
+                        raise RuntimeError('%s (%s): pointer argument %d is outside every buffer of the plan'
+                                           % (fname, s.name, ai))
             d = set()
             for b in rd + wr:
                 if b in last_writer:
@@ -1170,8 +1183,8 @@ class CompiledGraph(object):
     def _assign_streams(self, release_after=None):
         """Puts the second chain that starts from the input frame (ICNet's full-resolution
         branch) on a side stream, with events where the chains exchange data.
-        release_after (experiments only, see _setup_streams): index of a step of the main
-        chain the side chain waits for before it starts."""
+        release_after (tests and experiments): index of a step of the main chain the side
+        chain waits for before it starts, i.e. a fork in the middle of the pass."""
         deps, main_src = self._dependencies()
         for s in self.steps:
             s.stream, s.waits, s.signal = 0, [], None
@@ -1231,10 +1244,12 @@ class CompiledGraph(object):
 
     def _capture(self):
         if self.graph_exec is not None:
-            # destroyed with the plan, not here: tearing an executable graph down right after
-            # its last launch has completed and launching a new one next was seen to crash
-            # inside the HIP runtime now and then
-            self.retired_graphs.append(self.graph_exec)
+            # an executable graph may be torn down only when nothing of its last launch is
+            # still in flight on EITHER stream: the plan's stream alone being idle says
+            # nothing about the runtime's bookkeeping for the side branch, so the whole
+            # device is drained first
+            _lib.call('fss_device_sync')
+            _lib.call('fss_graph_destroy', self.graph_exec)
             self.graph_exec = None
         _lib.call('fss_capture_begin', self.sh)
         ex = ctypes.c_void_p()
@@ -1255,21 +1270,23 @@ class CompiledGraph(object):
         return (time.perf_counter() - t0) / reps
 
     def _setup_streams(self, tune=True):
-        """Side-stream schedule.  The side chain forks from the plan's stream at the start of
-        the pass and nowhere else: a fork in the middle of the main chain (a captured node
-        with one successor on each stream) produced replays in which a later node of the
-        main chain ran before its predecessor had finished, so that shape is not offered.
-        The two-stream graph is kept only if it is faster than the single-stream one AND
-        its replays reproduce the eager single-stream outputs bit for bit."""
+        """Side-stream schedule: the side chain forks from the plan's stream at the start of
+        the pass and joins at the first launch that needs its result.  The two-stream graph
+        is kept if it is faster than the single-stream one; its replays must reproduce the
+        eager single-stream outputs bit for bit, and a mismatch is an error (it would mean a
+        missing dependency edge or a kernel that misbehaves beside another one), never a
+        silent fallback.  `stream_choice` records what was decided and why."""
         self.side_stream = torch.cuda.Stream(device=self.device)
         self.sh_side = ctypes.c_void_p(self.side_stream.cuda_stream)
         self.fork_event = ctypes.c_void_p()
         _lib.call('fss_event_create', ctypes.byref(self.fork_event))
         self.events.append(self.fork_event)
         if not self._assign_streams(None):
+            self.stream_choice = 'single: the graph has no second chain'
             return False
         if not tune:
             self.two_streams = True
+            self.stream_choice = 'two: not timed'
             return True
         # reference: the eager single-stream pass that has just run (same input buffer)
         self.sync()
@@ -1281,16 +1298,18 @@ class CompiledGraph(object):
         self.two_streams = True
         self._capture()
         two_t = self._time_launches()
-        same = True
         for _ in range(3):
             self.launch()
             self.sync()
-            same = same and all(torch.equal(v.buf.view(torch.uint8), r.view(torch.uint8))
-                                for v, r in zip(outs, ref))
+            for v, r in zip(outs, ref):
+                if not torch.equal(v.buf.view(torch.uint8), r.view(torch.uint8)):
+                    raise RuntimeError('replays of the two-stream graph differ from the eager '
+                                       'single-stream pass')
         if os.environ.get('FSS_PLAN_DEBUG'):
-            print('two streams: %.3f ms, single stream %.3f ms, replays identical: %s'
-                  % (two_t * 1e3, single_t * 1e3, same), flush=True)
-        self.two_streams = same and two_t < single_t
+            print('two streams: %.3f ms, single stream %.3f ms' % (two_t * 1e3, single_t * 1e3), flush=True)
+        self.two_streams = two_t < single_t
+        self.stream_choice = '%s: two streams %.3f ms, one stream %.3f ms' % (
+            'two' if self.two_streams else 'single', two_t * 1e3, single_t * 1e3)
         self.release_after = None if self.two_streams else 'single'
         return self.two_streams
 
@@ -1341,9 +1360,8 @@ class CompiledGraph(object):
     def __del__(self):
         try:
             lib.fss_device_sync()
-            for g in self.retired_graphs + [self.graph_exec]:
-                if g is not None:
-                    lib.fss_graph_destroy(g)
+            if self.graph_exec is not None:
+                lib.fss_graph_destroy(self.graph_exec)
             for e in self.events:
                 lib.fss_event_destroy(e)
         except Exception:

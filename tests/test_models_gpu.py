@@ -283,7 +283,7 @@ def test_side_stream_and_stem_fusion_do_not_change_results(dtype):
                     ('unfused', dict(streams=1, fuse_stem=False))):
         cg = plan.CompiledGraph(g, outs, weights, dtype=dtype, **kw)
         if key == 'two':
-            assert cg.two_streams or cg.release_after == 'single'
+            assert cg.two_streams or cg.stream_choice.startswith('single: two streams'), cg.stream_choice
             assert any(s.stream == 1 for s in cg.steps), 'ICNet must have a side chain'
             assert any(s.kind == 'stem' for s in cg.steps)
         if key == 'unfused':
@@ -359,6 +359,8 @@ def test_every_launch_writes_only_its_own_outputs():
     bufs = {}
     for v in list(cg.vals.values()) + cg.temps + [cg.input_val]:
         bufs[v.buf.data_ptr()] = v.buf
+    for t in cg.workspaces:
+        bufs[t.data_ptr()] = t
 
     def buf_of(ptr):
         for bp, b in bufs.items():
@@ -380,3 +382,50 @@ def test_every_launch_writes_only_its_own_outputs():
         for bp, b in before.items():
             assert torch.equal(b.view(torch.uint8), bufs[bp].view(torch.uint8)), \
                 '%s (%s) wrote outside its outputs' % (s.name, s.kind)
+
+
+def test_side_chain_started_in_the_middle_of_the_pass():
+    """The side chain (here headed by the uint8 stem convolution of the full-resolution branch)
+    is released right before the pyramid pooling kernels, so that it shares the compute units
+    with them - the situation in which a build WITH packed-f32 VALU math (hipcc's SLP
+    vectorizer) lost blend terms in lanes 48-63 of pyramid_add_kernel's waves.  The shipped
+    build must reproduce the single-stream outputs of every launch bit for bit, launched
+    eagerly on two streams and replayed as a two-stream graph, and re-capturing (which tears
+    the previous executable graph down) must keep working."""
+    import torch
+    from fss import plan
+    arch, ext, fs, pf = 'icnet', 'dilated_resnet50', 1.0, [1.0, 2.0, 3.0, 4.0]
+    in_shape, pad_shape = (2, 1024, 2048, 3), (1025, 2049)
+    g, cfg, outs, weights = build(arch, ext, fs, pf, in_shape, pad_shape)
+    img = np.random.default_rng(12).integers(0, 256, in_shape).astype(np.uint8)
+    cg = plan.CompiledGraph(g, outs, weights, dtype='bfloat16', streams=1, commute_zoom=False,
+                            fuse_stem2=False)
+    cg.run(img)
+    bufs = {}
+    for v in list(cg.vals.values()) + cg.temps:
+        bufs[v.buf.data_ptr()] = v.buf
+    torch.cuda.synchronize()
+    ref = {p: b.clone() for p, b in bufs.items()}
+    fork = [i for i, s in enumerate(cg.steps) if s.kind == 'avgpool'][0] - 1
+    assert cg.steps[fork].kind == 'conv'
+    cg._setup_streams(tune=False)
+    assert cg._assign_streams(fork)
+    side = [s for s in cg.steps if s.stream == 1]
+    assert side and side[0].kind == 'stem'
+    cg.two_streams = True
+
+    def check(tag):
+        for it in range(4):
+            cg.launch()
+            cg.sync()
+            torch.cuda.synchronize()
+            for p, b in bufs.items():
+                assert torch.equal(b.view(torch.uint8), ref[p].view(torch.uint8)), \
+                    '%s, pass %d: a buffer of shape %s differs from the single-stream pass' % (tag, it, tuple(b.shape))
+
+    saved, cg.graph_exec = cg.graph_exec, None
+    check('eager two streams')
+    cg.graph_exec = saved
+    for round_ in range(3):                 # each capture destroys the previous executable
+        cg._capture()
+        check('two-stream graph %d' % round_)
