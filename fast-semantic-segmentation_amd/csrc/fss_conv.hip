@@ -84,10 +84,40 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 //            accumulator reg q holds C[4*g + q][r].
 // A float chunk is 4 k values, consumed by 4 f32 MFMAs with the same k permutation
 // on both operands.
+// Storage tag of the split-bfloat16 mode: tensors are float in memory and in LDS (everything
+// but the MFMA step is the float path), and each product a*b is formed on the bf16 matrix
+// pipe as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with a = a_hi + a_lo (a_hi = bf16(a),
+// a_lo = bf16(a - a_hi), the subtraction exact), which keeps about 16 mantissa bits per
+// operand: float-class results at three bf16 MFMAs per step instead of the 16x slower float
+// MFMAs.  Activations are split in registers; the weights arrive split by the caller (same
+// bytes as float: per 8 k values 8 bf16 high parts, then 8 bf16 remainders).
+struct f32s_t { float v; };
+template <> struct ElemTraits<f32s_t> {
+  static __device__ __forceinline__ float load(const f32s_t* p) { return p->v; }
+};
+
+// 8 floats (two 16-byte chunks) -> their bf16 high parts and bf16 remainders, packed 8 per uint4
+// in the element order (c0.x, c0.y, c0.z, c0.w, c1.x, ...) on both outputs.
+__device__ __forceinline__ void split8(const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) {
+  const unsigned f[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = __uint_as_float(f[2 * i]), b = __uint_as_float(f[2 * i + 1]);
+    // round to nearest even, so that the remainders (and the dropped lo*lo terms) have no
+    // systematic sign: truncation would bias every product the same way
+    h[i] = pack_bf16x2(a, b);
+    l[i] = pack_bf16x2(a - __uint_as_float(h[i] << 16), b - __uint_as_float(h[i] & 0xffff0000u));
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 template <typename T, int FM> struct Mma;
 template <> struct Mma<bf16_t, 32> {
   typedef f32x16 acc_t;
   static constexpr int NREG = 16;
+  static constexpr bool PAIRED = false;
   static __device__ __forceinline__ int row_of(int q, int g) { return (q & 3) + 8 * (q >> 2) + 4 * g; }
   static __device__ __forceinline__ void run(acc_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
@@ -97,6 +127,7 @@ template <> struct Mma<bf16_t, 32> {
 template <> struct Mma<bf16_t, 16> {
   typedef f32x4 acc_t;
   static constexpr int NREG = 4;
+  static constexpr bool PAIRED = false;
   static __device__ __forceinline__ int row_of(int q, int g) { return 4 * g + q; }
   static __device__ __forceinline__ void run(acc_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
@@ -106,6 +137,7 @@ template <> struct Mma<bf16_t, 16> {
 template <> struct Mma<float, 32> {
   typedef f32x16 acc_t;
   static constexpr int NREG = 16;
+  static constexpr bool PAIRED = false;
   static __device__ __forceinline__ int row_of(int q, int g) { return (q & 3) + 8 * (q >> 2) + 4 * g; }
   static __device__ __forceinline__ void run(acc_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
@@ -117,12 +149,35 @@ template <> struct Mma<float, 32> {
 template <> struct Mma<float, 16> {
   typedef f32x4 acc_t;
   static constexpr int NREG = 4;
+  static constexpr bool PAIRED = false;
   static __device__ __forceinline__ int row_of(int q, int g) { return 4 * g + q; }
   static __device__ __forceinline__ void run(acc_t& acc, const uint4& a, const uint4& b) {
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+
+// Split mode: the float chunks of two consecutive k steps (8 values per lane and operand, the
+// same k positions on both operands) feed one bf16 MFMA step per product term; the two small
+// terms are added first.
+template <> struct Mma<f32s_t, 32> : Mma<bf16_t, 32> {
+  static constexpr bool PAIRED = true;
+  static __device__ __forceinline__ void run3(acc_t& acc, const uint4& ahi, const uint4& alo,
+                                              const uint4& bhi, const uint4& blo) {
+    Mma<bf16_t, 32>::run(acc, alo, bhi);
+    Mma<bf16_t, 32>::run(acc, ahi, blo);
+    Mma<bf16_t, 32>::run(acc, ahi, bhi);
+  }
+};
+template <> struct Mma<f32s_t, 16> : Mma<bf16_t, 16> {
+  static constexpr bool PAIRED = true;
+  static __device__ __forceinline__ void run3(acc_t& acc, const uint4& ahi, const uint4& alo,
+                                              const uint4& bhi, const uint4& blo) {
+    Mma<bf16_t, 16>::run(acc, alo, bhi);
+    Mma<bf16_t, 16>::run(acc, ahi, blo);
+    Mma<bf16_t, 16>::run(acc, ahi, bhi);
   }
 };
 
@@ -394,6 +449,31 @@ conv_igemm_kernel(const ConvArgs a) {
     issue(kt + NSTAGE - 1, fill);
     const char* pa = smem + slot * STAGE_BYTES + (wm * WTM + lrow) * BKB;
     const char* pb = smem + slot * STAGE_BYTES + BM * BKB + (wn * WTN + lrow) * BKB;
+    if constexpr (MMA::PAIRED) {
+      // split mode: per MFMA step lane group lg owns the 8 consecutive k values of the chunk
+      // pair (2q, 2q + 1), q = LG * step + lg: 8 floats of A (split here), and the
+      // pre-split weights, whose rows hold per 8 k values their 8 bf16 high parts (chunk 2q)
+      // followed by their 8 bf16 remainders (chunk 2q + 1)
+      static_assert(KSTEPS % 2 == 0 && !HEAD, "split mode pairs the chunks of a tile row");
+#pragma unroll
+      for (int s = 0; s < KSTEPS / 2; ++s) {
+        const int o0 = ((2 * (LG * s + lg)) ^ swz) * 16, o1 = ((2 * (LG * s + lg) + 1) ^ swz) * 16;
+        uint4 ahi[MI], alo[MI], bhi[NI], blo[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+          split8(*reinterpret_cast<const uint4*>(pa + i * FM * BKB + o0),
+                 *reinterpret_cast<const uint4*>(pa + i * FM * BKB + o1), ahi[i], alo[i]);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          bhi[j] = *reinterpret_cast<const uint4*>(pb + j * FM * BKB + o0);
+          blo[j] = *reinterpret_cast<const uint4*>(pb + j * FM * BKB + o1);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) MMA::run3(acc[i][j], ahi[i], alo[i], bhi[j], blo[j]);
+      }
+    } else {
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       uint4 fa[MI], fb[NI];
@@ -410,6 +490,7 @@ conv_igemm_kernel(const ConvArgs a) {
           if constexpr (HEAD) MMA::run(acc[i][j], fb[j], fa[i]);
           else MMA::run(acc[i][j], fa[i], fb[j]);
         }
+    }
     }
     slot = slot + 1 == NSTAGE ? 0 : slot + 1;
     fill = fill + 1 == NSTAGE ? 0 : fill + 1;
@@ -674,6 +755,11 @@ static int launch_conv_impl(ConvArgs& a, hipStream_t stream) {
 template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int BKB, int NSTAGE, int FM>
 static int launch_conv(ConvArgs& a, hipStream_t stream) {
   constexpr int BK = BKB / (int)sizeof(T);
+  if constexpr (std::is_same<T, f32s_t>::value && (BKB / (16 * (64 / FM))) % 2 != 0) {
+    set_error("fss_conv2d_nhwc: FSS_F32_BF16X3 needs a configuration with an even number of k steps per "
+              "tile (bytes of K per row a multiple of 2048 / mfma_edge)");
+    return 2;
+  } else {
   if (a.Cin % BK == 0 && a.Cin2 % BK == 0 && a.KH * a.KW <= 62)
     return launch_conv_impl<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, FM, true>(a, stream);
   if (a.Cin2 > 0) {
@@ -681,6 +767,7 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
     return 2;
   }
   return launch_conv_impl<T, TO, BM, BN, WAVES_M, WAVES_N, BKB, NSTAGE, FM, false>(a, stream);
+  }
 }
 
 // Tile configurations.  Every configuration is legal for every layer (tiles
@@ -821,12 +908,13 @@ static int conv_setup(const fss_conv_desc* d, const void* x, const void* x2, int
                       const void* w_packed, const float* bias, const void* residual, void* y,
                       ConvArgs& a) {
   FSS_REQUIRE(d && x && w_packed && y, "null argument");
-  FSS_REQUIRE(d->in_dtype == FSS_F32 || d->in_dtype == FSS_BF16, "bad in_dtype");
+  FSS_REQUIRE(d->in_dtype == FSS_F32 || d->in_dtype == FSS_BF16 || d->in_dtype == FSS_F32_BF16X3,
+              "bad in_dtype");
   FSS_REQUIRE(d->out_dtype == FSS_F32 || d->out_dtype == FSS_BF16, "bad out_dtype");
-  FSS_REQUIRE(!(d->in_dtype == FSS_F32 && d->out_dtype == FSS_BF16),
+  FSS_REQUIRE(!(d->in_dtype != FSS_BF16 && d->out_dtype == FSS_BF16),
               "f32 input with bf16 output is not supported");
-  const int epc = d->in_dtype == FSS_F32 ? 4 : 8;
-  const int esz = d->in_dtype == FSS_F32 ? 4 : 2;
+  const int epc = d->in_dtype != FSS_BF16 ? 4 : 8;
+  const int esz = d->in_dtype != FSS_BF16 ? 4 : 2;
   FSS_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "bad shape");
   FSS_REQUIRE(d->cin % epc == 0, "cin must be a multiple of 16 bytes of elements");
   FSS_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dilation > 0, "bad filter");
@@ -875,6 +963,7 @@ extern "C" int fss_conv2d_dual_nhwc(const fss_conv_desc* d, const void* x, const
   if (int rc = conv_setup(d, x, x2, cin2, w_packed, bias, residual, y, a)) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (d->in_dtype == FSS_F32) return dispatch_conv<float, float>(a, d->config, s);
+  if (d->in_dtype == FSS_F32_BF16X3) return dispatch_conv<f32s_t, float>(a, d->config, s);
   if (d->out_dtype == FSS_BF16) return dispatch_conv<bf16_t, bf16_t>(a, d->config, s);
   return dispatch_conv<bf16_t, float>(a, d->config, s);
 }

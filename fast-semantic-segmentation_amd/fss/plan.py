@@ -46,6 +46,21 @@ def f32_to_bf16_bits(a):
     return u.astype(np.uint16)
 
 
+def f32_split_bf16_rows(wp):
+    """Packed float32 weights [cout_pad, k_pad] -> the FSS_F32_BF16X3 form: per 8 consecutive k
+    values of a row their 8 bfloat16 high parts, then their 8 bfloat16 remainders (uint16
+    array of shape [cout_pad, 2 * k_pad], the same bytes as the float32 matrix)."""
+    wp = np.ascontiguousarray(wp, dtype=np.float32)
+    hi = f32_to_bf16_bits(wp)
+    hi_f = (hi.astype(np.uint32) << 16).view(np.float32)
+    lo = f32_to_bf16_bits(wp - hi_f)
+    r, k = wp.shape
+    out = np.empty((r, k // 8, 2, 8), np.uint16)
+    out[:, :, 0, :] = hi.reshape(r, k // 8, 8)
+    out[:, :, 1, :] = lo.reshape(r, k // 8, 8)
+    return out.reshape(r, 2 * k)
+
+
 class LNode(object):
     """Private, mutable copy of a graph node used during lowering."""
 
@@ -117,7 +132,11 @@ class CompiledGraph(object):
                  fuse_head=True, collapse_zooms=True, commute_zoom=None, fuse_zoom_residual=None):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
-        self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16'}[dtype]
+        # 'float32x3': float32 tensors everywhere; the convolutions form their products on the
+        # bf16 matrix pipe from bf16 hi/lo splits of both operands (FSS_F32_BF16X3)
+        self.split = dtype in ('float32x3', 'f32x3')
+        self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16',
+                   'float32x3': 'f32', 'f32x3': 'f32'}[dtype]
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
         self.weights = weights
         self.outputs = list(outputs)
@@ -232,6 +251,10 @@ class CompiledGraph(object):
         n, h, w, c = shape
         return torch.empty((n, h, w, phys_c if phys_c is not None else c),
                            dtype=_TORCH_DT[dt], device=self.device)
+
+    def _in_code(self, dt):
+        """in_dtype code of a convolution whose input is stored as `dt`."""
+        return _lib.F32_BF16X3 if (dt == 'f32' and self.split) else _CODE[dt]
 
     def _dev_f32(self, arr):
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
@@ -559,6 +582,8 @@ class CompiledGraph(object):
             Wp[:cout, :k] = Wt
             if dt == 'bf16':
                 dev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+            elif self.split:
+                dev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
             else:
                 dev = torch.from_numpy(Wp).to(self.device)
             self.keepalive.append(dev)
@@ -586,7 +611,7 @@ class CompiledGraph(object):
             y = Val(self._alloc((nn, oh, ow, cout), dt), (nn, oh, ow, cout), dt)
             d = _lib.ConvDesc(n=nn, h=hh, w=ww, cin=cin, cout=cout, kh=3, kw=3, stride=1, dilation=1,
                               pad_top=pt, pad_left=pl, ho=oh, wo=ow, act=_lib.ACT_CODES[None],
-                              in_dtype=_CODE[dt], out_dtype=_CODE[dt], y_ld=y.ld, res_ld=0,
+                              in_dtype=self._in_code(dt), out_dtype=_CODE[dt], y_ld=y.ld, res_ld=0,
                               k_pad=k_pad, cout_pad=cout_pad)
             self._emit('conv', base + tag, 'fss_conv2d_nhwc',
                        (ctypes.byref(d), v.ptr, wB.data_ptr(), None, None, y.ptr, self.sh),
@@ -610,7 +635,7 @@ class CompiledGraph(object):
         name = base + '+' + A.attrs['weights'].rsplit('/', 2)[-2]
         d = _lib.ConvDesc(n=n, h=ho, w=wo, cin=cin2, cout=cout, kh=1, kw=1, stride=1, dilation=1,
                           pad_top=0, pad_left=0, ho=ho, wo=wo, act=_lib.ACT_CODES[act],
-                          in_dtype=_CODE[dt], out_dtype=_CODE[dt], y_ld=cout, res_ld=r.ld if r else 0,
+                          in_dtype=self._in_code(dt), out_dtype=_CODE[dt], y_ld=cout, res_ld=r.ld if r else 0,
                           k_pad=k_pad2, cout_pad=cout_pad)
         if head is not None:
             # the classifier launch interpolates the source-resolution results itself
@@ -663,6 +688,8 @@ class CompiledGraph(object):
         Wp[:cout, kh * kw * cin:k] = WA.reshape(cin2, cout).T
         if x.dt == 'bf16':
             wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+        elif self.split:
+            wdev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
         else:
             wdev = torch.from_numpy(Wp).to(self.device)
         self.keepalive.append(wdev)
@@ -673,7 +700,7 @@ class CompiledGraph(object):
         if head is not None:
             d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
                               dilation=b['rate'], pad_top=b['pad_top'], pad_left=b['pad_left'],
-                              ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE[x.dt],
+                              ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=self._in_code(x.dt),
                               out_dtype=_CODE[x.dt], y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
             return self._emit_head(head, d, x, x2, cin2, wdev, bdev, cout, k, name)
         out = Val(self._alloc(B.shape, x.dt), B.shape, x.dt)
@@ -681,7 +708,7 @@ class CompiledGraph(object):
             self.vals[node] = out
         d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
                           dilation=b['rate'], pad_top=b['pad_top'], pad_left=b['pad_left'],
-                          ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE[x.dt],
+                          ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=self._in_code(x.dt),
                           out_dtype=_CODE[x.dt], y_ld=out.ld, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
         nbytes = (n * h * w * cin + n * ho * wo * cin2 + cout * k + n * ho * wo * cout) * _ESZ[x.dt]
         self._emit('conv', name, 'fss_conv2d_dual_nhwc',
@@ -733,6 +760,8 @@ class CompiledGraph(object):
         Wp[:cout, :kh * kw * pc] = Wt.transpose(3, 0, 1, 2).reshape(cout, -1)
         if in_dt == 'bf16':
             wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+        elif self.split:
+            wdev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
         else:
             wdev = torch.from_numpy(Wp).to(self.device)
         self.keepalive.append(wdev)
@@ -744,7 +773,7 @@ class CompiledGraph(object):
         if head is not None:
             d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc, cout=cout, kh=kh, kw=kw, stride=1,
                               dilation=a['rate'], pad_top=a['pad_top'], pad_left=a['pad_left'],
-                              ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE[in_dt],
+                              ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=self._in_code(in_dt),
                               out_dtype=_CODE[in_dt], y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
             return self._emit_head(head, d, x, None, 0, wdev, bdev, cout, kh * kw * cin,
                                    a['weights'].rsplit('/', 1)[0])
@@ -761,7 +790,7 @@ class CompiledGraph(object):
             self.vals[ln] = out
         d = _lib.ConvDesc(n=n, h=h, w=w, cin=pc, cout=cout, kh=kh, kw=kw, stride=a['stride'],
                           dilation=a['rate'], pad_top=a['pad_top'], pad_left=a['pad_left'],
-                          ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE[in_dt],
+                          ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=self._in_code(in_dt),
                           out_dtype=_CODE[out_dt], y_ld=out.ld, res_ld=res.ld if res else 0,
                           k_pad=k_pad, cout_pad=cout_pad)
         nbytes = ((n * h * w * pc + cout * kh * kw * pc) * _ESZ[in_dt]
@@ -1074,7 +1103,7 @@ class CompiledGraph(object):
         candidates, tile_n = [], {}
         for cfg in range(1, ncfg + 1):
             _lib.call('fss_conv_config_info', cfg, info)
-            if info[6] == self.mfma_edge:
+            if info[6] == self.mfma_edge and not (self.split and (info[4] // (16 * (64 // info[6]))) % 2):
                 candidates.append(cfg)
                 tile_n[cfg] = info[1]
         e0 = e1 = None

@@ -53,3 +53,31 @@ def make_weights(variables, seed=1234, input_std=70.0):
             raise ValueError('no synthetic rule for variable %s' % name)
         out[name] = v.astype(np.float32)
     return out
+
+
+def make_weights_survey(variables, seed=1234):
+    """The plain recipe: every convolution kernel He-normal N(0, 2 / fan_in) with no special
+    cases, batch norm gamma ~ U(0.5, 1.5), beta ~ N(0, 0.1), moving_mean ~ N(0, 0.1),
+    moving_variance ~ U(0.5, 1.5), biases ~ N(0, 0.1).  Unlike make_weights nothing keeps the
+    activations O(1): the residual trunk grows from unit to unit and the relu6 layers of the
+    head largely saturate, so label maps have large uniform regions."""
+    out = {}
+    for name, shape in variables.items():
+        rng = _rng(seed, name)
+        leaf = name.rsplit('/', 1)[-1]
+        if leaf == 'weights':
+            kh, kw, cin, _ = shape
+            v = rng.normal(0.0, np.sqrt(2.0 / (kh * kw * cin)), shape)
+        elif leaf == 'depthwise_weights':
+            kh, kw, _, _ = shape
+            v = rng.normal(0.0, np.sqrt(2.0 / (kh * kw)), shape)
+        elif leaf == 'gamma':
+            v = rng.uniform(0.5, 1.5, shape)
+        elif leaf in ('beta', 'moving_mean', 'biases'):
+            v = rng.normal(0.0, 0.1, shape)
+        elif leaf == 'moving_variance':
+            v = rng.uniform(0.5, 1.5, shape)
+        else:
+            raise ValueError('no synthetic rule for variable %s' % name)
+        out[name] = v.astype(np.float32)
+    return out

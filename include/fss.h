@@ -29,6 +29,15 @@ extern "C" {
 
 #define FSS_F32 0
 #define FSS_BF16 1
+/* fss_conv_desc.in_dtype only: float tensors exactly as FSS_F32, but every product is formed on
+ * the bf16 matrix pipe from a two-way bf16 split of both operands (a_hi*b_hi + a_hi*b_lo +
+ * a_lo*b_hi with hi = bf16(v), lo = bf16(v - hi), float accumulation): about 16 mantissa bits
+ * per operand, i.e. results of float quality (well inside 1e-3 of the logit scale) at several
+ * times the speed of the float MFMAs.  Activations, residual, bias and output are float; the
+ * packed weights have the FSS_F32 dimensions and byte size, but every 8 consecutive k values
+ * of a row are stored as their 8 bf16 high parts followed by their 8 bf16 remainders.
+ * Needs a tile configuration with an even number of k steps per tile. */
+#define FSS_F32_BF16X3 2
 
 #define FSS_ACT_NONE 0
 #define FSS_ACT_RELU 1
@@ -82,7 +91,8 @@ typedef struct fss_conv_desc {
   int32_t pad_top, pad_left; /* zero padding before the first row / column */
   int32_t ho, wo;            /* output spatial size                        */
   int32_t act;               /* FSS_ACT_*                                  */
-  int32_t in_dtype;          /* FSS_F32 | FSS_BF16 (x, weights, residual)  */
+  int32_t in_dtype;          /* FSS_F32 | FSS_BF16 (x, weights, residual) |
+                                FSS_F32_BF16X3 (float storage, split-bf16 MFMA) */
   int32_t out_dtype;         /* FSS_F32 | FSS_BF16                         */
   int32_t y_ld;              /* output pixel stride in elements (>= cout)  */
   int32_t res_ld;            /* residual pixel stride in elements          */

@@ -6,9 +6,15 @@ import numpy as np
 import torch
 
 from fss import _lib
-from fss.plan import f32_to_bf16_bits
+from fss.plan import f32_to_bf16_bits, f32_split_bf16_rows
 
-DT = {'f32': (_lib.F32, torch.float32, 4), 'bf16': (_lib.BF16, torch.bfloat16, 8)}
+# 'f32x3': float32 tensors; convolutions take them as FSS_F32_BF16X3 (split-bf16 products)
+DT = {'f32': (_lib.F32, torch.float32, 4), 'bf16': (_lib.BF16, torch.bfloat16, 8),
+      'f32x3': (_lib.F32, torch.float32, 4)}
+
+
+def conv_in_code(dt):
+    return _lib.F32_BF16X3 if dt == 'f32x3' else DT[dt][0]
 
 
 def bf16_round(a):
@@ -37,6 +43,8 @@ def pack_conv_weights(w, dt, cin_phys=None):
     wp[:cout, :kh * kw * pc] = w.transpose(3, 0, 1, 2).reshape(cout, -1)
     if dt == 'bf16':
         dev = torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
+    elif dt == 'f32x3':
+        dev = torch.from_numpy(f32_split_bf16_rows(wp).view(np.int16)).cuda()
     else:
         dev = torch.from_numpy(wp).cuda()
     return dev, k_pad, cout_pad
@@ -57,7 +65,7 @@ def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw
     y = torch.full((n, ho, wo, ld), -77.0, dtype=DT[out_dt][1], device='cuda')
     d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride,
                       dilation=rate, pad_top=pads[0], pad_left=pads[1], ho=ho, wo=wo,
-                      act=_lib.ACT_CODES[act], in_dtype=DT[dt][0], out_dtype=DT[out_dt][0],
+                      act=_lib.ACT_CODES[act], in_dtype=conv_in_code(dt), out_dtype=DT[out_dt][0],
                       y_ld=ld, res_ld=cout, k_pad=k_pad, cout_pad=cout_pad, config=config)
     torch.cuda.synchronize()
     _lib.call('fss_conv2d_nhwc', ctypes.byref(d), xd.data_ptr(), wdev.data_ptr(),
@@ -85,6 +93,8 @@ def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, 
     wp[:cout, kh * kw * cin:k] = w2.reshape(cin2, cout).T
     if dt == 'bf16':
         wdev = torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
+    elif dt == 'f32x3':
+        wdev = torch.from_numpy(f32_split_bf16_rows(wp).view(np.int16)).cuda()
     else:
         wdev = torch.from_numpy(wp).cuda()
     xd, x2d = to_dev(x, dt), to_dev(x2, dt)
@@ -92,7 +102,7 @@ def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, 
     y = torch.full((n, ho, wo, cout), -77.0, dtype=DT[dt][1], device='cuda')
     d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride,
                       dilation=rate, pad_top=pads[0], pad_left=pads[1], ho=ho, wo=wo,
-                      act=_lib.ACT_CODES[act], in_dtype=DT[dt][0], out_dtype=DT[dt][0],
+                      act=_lib.ACT_CODES[act], in_dtype=conv_in_code(dt), out_dtype=DT[dt][0],
                       y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad, config=config)
     torch.cuda.synchronize()
     _lib.call('fss_conv2d_dual_nhwc', ctypes.byref(d), xd.data_ptr(), x2d.data_ptr(), cin2,

@@ -67,7 +67,7 @@ def _conv_pads(h, wd, k, stride, rate, mode):
 
 
 @pytest.mark.parametrize('case', CONV_CASES)
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 def test_conv2d(case, dt):
     gu = _gu()
     n, h, wd, cin, cout, k, stride, rate, mode = case
@@ -85,7 +85,7 @@ def test_conv2d(case, dt):
     _close(got, ref, 2e-4, 'conv %s %s' % (dt, case,))
 
 
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 @pytest.mark.parametrize('act', [None, 'relu', 'relu6'])
 def test_conv2d_epilogue(dt, act):
     """bias + residual + activation, output written into a wider pixel stride."""
@@ -101,10 +101,10 @@ def test_conv2d_epilogue(dt, act):
     ref = O.conv2d(x, w, 1, 1, 'SAME', np.float64) + bias + res
     ref = {'relu': O.relu, 'relu6': O.relu6, None: lambda v: v}[act](ref)
     got = gu.conv2d(x, w, bias, res, 1, 1, (1, 1), (h, wd), act, dt, y_ld=cout + 16)
-    _close(got, ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'conv epilogue %s %s' % (dt, act))
+    _close(got, ref, 2e-4 if dt != 'bf16' else 1.0 / 128, 'conv epilogue %s %s' % (dt, act))
 
 
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 def test_conv2d_configs_agree_bitwise(dt):
     """Tile configurations with the same MFMA shape accumulate each output over k
     in the same order: results must be bit-identical within a shape class, and
@@ -119,18 +119,24 @@ def test_conv2d_configs_agree_bitwise(dt):
                           gu.bf16_round(w) if dt == 'bf16' else w, 1, 2, 'SAME', np.float64) + bias)
     by_shape = {}
     for cfg in range(0, L.lib.fss_conv_config_count() + 1):
-        out = gu.conv2d(x, w, bias, None, 1, 2, (2, 2), (h, wd), 'relu', dt, config=cfg)
-        _close(out, ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'conv config %d' % cfg)
+        info = (ctypes.c_int * 7)()
         if cfg:
-            info = (ctypes.c_int * 7)()
             L.call('fss_conv_config_info', cfg, info)
+            if dt == 'f32x3' and (info[4] // (16 * (64 // info[6]))) % 2:
+                # the split mode pairs k steps: an odd number per tile is rejected
+                with pytest.raises(L.FssError, match='even number of k steps'):
+                    gu.conv2d(x, w, bias, None, 1, 2, (2, 2), (h, wd), 'relu', dt, config=cfg)
+                continue
+        out = gu.conv2d(x, w, bias, None, 1, 2, (2, 2), (h, wd), 'relu', dt, config=cfg)
+        _close(out, ref, 2e-4 if dt != 'bf16' else 1.0 / 128, 'conv config %d' % cfg)
+        if cfg:
             assert info[0] % 32 == 0 and info[1] % 32 == 0 and info[6] in (16, 32)
             first = by_shape.setdefault(info[6], out)
             assert np.array_equal(out, first), 'config %d differs inside its shape class' % cfg
     assert sorted(by_shape) == [16, 32]
 
 
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 def test_conv2d_dual_is_the_sum_of_two_convolutions(dt):
     """fss_conv2d_dual_nhwc = relu(conv3x3_dilated(x) + conv1x1(x2) + bias) (the cascade
     feature fusion) against the oracle's two convolutions added in float64; every tile
@@ -148,11 +154,14 @@ def test_conv2d_dual_is_the_sum_of_two_convolutions(dt):
     ref = O.relu(O.conv2d(x, w, 1, 2, 'SAME', np.float64) + O.conv2d(x2, w2, 1, 1, 'SAME', np.float64) + bias)
     by_shape = {}
     for cfg in range(0, L.lib.fss_conv_config_count() + 1):
-        out = gu.conv2d_dual(x, w, x2, w2, bias, 1, 2, (2, 2), (h, wd), 'relu', dt, config=cfg)
-        _close(out, ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'dual conv config %d' % cfg)
+        info = (ctypes.c_int * 7)()
         if cfg:
-            info = (ctypes.c_int * 7)()
             L.call('fss_conv_config_info', cfg, info)
+            if dt == 'f32x3' and (info[4] // (16 * (64 // info[6]))) % 2:
+                continue        # odd number of k steps per tile: not offered in the split mode
+        out = gu.conv2d_dual(x, w, x2, w2, bias, 1, 2, (2, 2), (h, wd), 'relu', dt, config=cfg)
+        _close(out, ref, 2e-4 if dt != 'bf16' else 1.0 / 128, 'dual conv config %d' % cfg)
+        if cfg:
             first = by_shape.setdefault(info[6], out)
             assert np.array_equal(out, first), 'config %d differs inside its shape class' % cfg
 
