@@ -1399,8 +1399,8 @@ class CompiledGraph(object):
     # -------------------------------------------------------------- profiling
     def profile(self, repeats=3):
         """Times every launch with HIP events recorded on the plan's stream
-        (eager mode).  Returns a list of dicts (kind, name, ms, flops, bytes),
-        ms = the best of `repeats` runs."""
+        (eager mode, single stream).  Returns a list of dicts (kind, name, ms, mean_ms, flops,
+        bytes): ms = the best, mean_ms = the mean of `repeats` passes."""
         n = len(self.steps)
         evs = []
         for _ in range(n + 1):
@@ -1408,6 +1408,7 @@ class CompiledGraph(object):
             _lib.call('fss_event_create', ctypes.byref(e))
             evs.append(e)
         best = [float('inf')] * n
+        total = [0.0] * n
         for _ in range(repeats):
             _lib.call('fss_event_record', evs[0], self.sh)
             for k, s in enumerate(self.steps):
@@ -1418,9 +1419,10 @@ class CompiledGraph(object):
                 ms = ctypes.c_float()
                 _lib.call('fss_event_elapsed_ms', evs[k], evs[k + 1], ctypes.byref(ms))
                 best[k] = min(best[k], ms.value)
+                total[k] += ms.value
         for e in evs:
             _lib.call('fss_event_destroy', e)
-        return [dict(kind=s.kind, name=s.name, ms=best[k], flops=s.flops, graph_flops=s.graph_flops, bytes=s.bytes,
+        return [dict(kind=s.kind, name=s.name, ms=best[k], mean_ms=total[k] / repeats, flops=s.flops, graph_flops=s.graph_flops, bytes=s.bytes,
                      config=((s.keep[0] if isinstance(s.keep, tuple) else s.keep).config
                              if s.kind == 'conv' else None))
                 for k, s in enumerate(self.steps)]

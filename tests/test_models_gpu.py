@@ -89,8 +89,14 @@ def test_forward_parity(case, dtype):
         assert err <= 1e-3
         assert agree >= 0.999
     else:
+        # bfloat16 meets the logit tolerance but NOT the 99.9 % label gate on these weights: the
+        # classifier of synth.make_weights is zero-mean, so ~1 % of the pixels have a top-2
+        # margin below 1e-3 of the logit scale and ~9 % below 1e-2, and bf16 rounding noise
+        # (0.5-0.8 % rms of every activation from the first residual block on) flips 1-2 % of
+        # them.  The floor below is what is measured, not what is required; 'float32x3' is the
+        # mode that meets the gate (asserted above).
         assert err <= 2e-2
-        # bf16 rounding may flip pixels whose top-2 margin is below the error bound
+        assert agree >= 0.98
         s = np.sort(ref, axis=3)
         clear = (s[..., -1] - s[..., -2]) > 2 * 2e-2 * scale
         assert np.array_equal(labels[..., 0][clear], ref_lab[clear])
@@ -103,6 +109,29 @@ def test_forward_parity(case, dtype):
     cg.launch()
     cg.sync()
     assert np.array_equal(cg.fetch(outs[1]), labels)
+
+
+@pytest.mark.parametrize('case', CASES[:3], ids=lambda c: '%s-%s-%s' % (c[0], c[1], c[2]))
+def test_bf16_labels_on_plain_he_normal_weights(case):
+    """The same comparison on weights drawn by the plain recipe (synth.make_weights_survey: He-normal
+    kernels, batch norm gamma ~ U(0.5, 1.5), nothing zero-mean): label regions are larger, margins
+    wider; bfloat16 still misses the 99.9 % label gate (0.996-0.999 measured), so it is held to the logit
+    tolerance and a floor of 99 %, float32x3 to every stated tolerance."""
+    from fss import plan, synth
+    arch, ext, fs, pf, in_shape, pad_shape = case
+    g, cfg, outs, _ = build(arch, ext, fs, pf, in_shape, pad_shape)
+    weights = synth.make_weights_survey(g.variables, seed=1234)
+    img = np.random.default_rng(0).integers(0, 256, in_shape).astype(np.uint8)
+    ref = oracle_logits(arch, ext, fs, pf, img, pad_shape, weights)
+    ref_lab = O.argmax_channels(ref)
+    scale = float(np.abs(ref).max())
+    for dtype, tol, floor in (('bfloat16', 2e-2, 0.99), ('float32x3', 1e-3, 0.999)):
+        logits, labels = plan.CompiledGraph(g, outs, weights, dtype=dtype).run(img)
+        err = float(np.abs(logits - ref).max()) / scale
+        agree = float((labels[..., 0] == ref_lab).mean())
+        print('%s %s plain weights: logit err %.3g of scale, argmax agreement %.5f' % (case[:3], dtype, err, agree))
+        assert err <= tol
+        assert agree >= floor
 
 
 def test_classifier_commute_is_exact_enough():
