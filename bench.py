@@ -51,14 +51,14 @@ def measured_conv_traffic(batch, n_conv, dtype):
     return per_frame * batch / n_conv
 
 
-def build_plan(batch, dtype, with_labels=True):
+def build_plan(batch, dtype, with_labels=True, config=CONFIG):
     from google.protobuf import text_format
     from protos import pipeline_pb2
     from builders import model_builder
     from fss import graph as G, synth, plan
     from libs import evaluator
     cfg = pipeline_pb2.PipelineConfig()
-    with open(os.path.join(PKG, 'configs', CONFIG)) as f:
+    with open(os.path.join(PKG, 'configs', config)) as f:
         text_format.Merge(f.read(), cfg)
     g = G.reset_default_graph()
     num_classes, model = model_builder.build(cfg.model, is_training=False)

@@ -83,3 +83,80 @@ def test_full_size_bf16_properties():
     logits1, labels1 = cg1.run(frames[1:2])
     assert np.array_equal(logits1[0], logits2[1])
     assert np.array_equal(labels1[0], labels2[1])
+
+
+def _scores_of(cg):
+    """The classifier scores the fused zoom + argmax launch reads, as a host array
+    [n, h, w, classes] (the tensor the plan computes in place of the reference's zoomed logits)."""
+    import torch
+    i = [k for k, f in enumerate(cg.step_fname) if f == 'fss_upsample_argmax'][0]
+    a = cg.steps[i].args
+    ptr, n, h, w, c, ld = a[0], a[3], a[4], a[5], a[6], a[7]
+    for v in cg.vals.values():
+        if v.buf.data_ptr() == ptr:
+            cg.sync()
+            torch.cuda.synchronize()
+            return v.buf.reshape(n, h, w, ld)[..., :c].float().cpu().numpy()
+    raise AssertionError('scores buffer not found')
+
+
+@pytest.mark.parametrize('config,fs', [('single_stage_icnet_1.0_1025_resnet_v1.config', 1.0),
+                                       ('two_stage_icnet_0.5_1025_resnet_v1_stage_2.config', 0.5)],
+                         ids=['icnet_1.0', 'icnet_0.5'])
+def test_benchmarked_plan_at_full_size_matches_oracle(config, fs):
+    """The plan bench.py times - evaluator graph, 1025x2049, 8 frames per launch, so that the
+    fusion convolutions run in front of their zoom, the classifier sits in the last fusion's
+    epilogue with the interpolated residual, the two zooms are one and two streams are on -
+    against the numpy oracle on its first and last frame: classifier scores (zoomed x2 on the
+    host, which is where the reference applies the classifier) within the stated tolerance of
+    the dtype, labels as stated for float32x3 and as measured for bfloat16; and against the
+    small-batch plan (fusion convolutions on the zoomed grid, stored residual)."""
+    import bench
+    from fss import plan
+    from oracle import nets
+    B = 8
+    rng = np.random.default_rng(21)
+    frames = rng.integers(0, 256, (B, 1024, 2048, 3)).astype(np.uint8)
+    refs = {}
+    for dtype, tol, floor in (('bfloat16', 2e-2, 0.97), ('float32x3', 1e-3, 0.999)):
+        cg, pred, _, weights = bench.build_plan(B, dtype, config=config)
+        names = [s.name for s in cg.steps]
+        assert any(n.endswith('@source') for n in names), 'fusion convs must run at the source resolution'
+        assert cg.two_streams or cg.stream_choice.startswith('single: two streams'), cg.stream_choice
+        if dtype == 'bfloat16':
+            head = [k for k, f in enumerate(cg.step_fname) if f == 'fss_conv2d_dual_head_nhwc']
+            assert head and cg.steps[head[0]].args[7] is not None, 'classifier epilogue with interpolated residual'
+        labels = cg.run(frames)[0]
+        scores = _scores_of(cg)
+        del cg
+        for f in (0, B - 1):
+            if f not in refs:
+                x = nets.preprocess(O.pad_to_bounding_box(frames[f:f + 1].astype(np.float32), *PAD), 'dilated_resnet50')
+                refs[f] = nets.icnet_predict(nets.Params(weights), x, filter_scale=int(round(1.0 / fs)),
+                                             return_all=True)
+            ref, taps = refs[f]
+            low = taps['logits_lowres']
+            scale = float(np.abs(low).max())
+            zoomed = O.resize_bilinear(scores[f:f + 1], low.shape[1], low.shape[2], True)
+            err = float(np.abs(zoomed - low).max()) / scale
+            ref_lab = O.argmax_channels(ref)
+            agree = float((labels[f, ..., 0] == ref_lab[0]).mean())
+            print('%s %s frame %d of %d: score err %.3g of scale, argmax agreement %.5f' % (config[:22], dtype, f, B, err, agree))
+            assert err <= tol
+            assert agree >= floor
+            if dtype == 'bfloat16':
+                s_ = np.sort(ref, axis=3)
+                clear = (s_[..., -1] - s_[..., -2]) > 2 * 2e-2 * float(np.abs(ref).max())
+                assert np.array_equal(labels[f, ..., 0][clear[0]], ref_lab[0][clear[0]])
+        if dtype == 'bfloat16':
+            # the small-batch plan of the same model: same scores to a few bf16 roundings
+            cg1, _, _, _ = bench.build_plan(1, dtype, config=config)
+            assert not any(s.name.endswith('@source') for s in cg1.steps)
+            labels1 = cg1.run(frames[:1])[0]
+            scores1 = _scores_of(cg1)
+            del cg1
+            sc = float(np.abs(scores1).max())
+            d = float(np.abs(scores1[0] - scores[0]).max()) / sc
+            same = float((labels1[0] == labels[0]).mean())
+            print('  batch-8 plan vs batch-1 plan: scores differ by %.3g of scale, labels agree %.5f' % (d, same))
+            assert d <= 2e-2 and same >= 0.97
