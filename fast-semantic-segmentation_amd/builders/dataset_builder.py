@@ -31,7 +31,10 @@ def decode_example(serialized):
     return image, label.astype(np.uint8)
 
 
-def build(input_reader_config):
+def build(input_reader_config, shard=None, limit=None):
+    """shard = (rank, world): only records whose index (in file order, over all files) is
+    congruent to rank modulo world are decoded and yielded, the others are skipped before
+    any PNG / JPEG decoding; limit = number of records (over all ranks) to consider."""
     if not isinstance(input_reader_config, input_reader_pb2.InputReader):
         raise ValueError('input_reader_config not of type input_reader_pb2.InputReader.')
     reader_config = input_reader_config.tf_record_input_reader
@@ -43,8 +46,15 @@ def build(input_reader_config):
     if input_reader_config.shuffle:
         logging.info('input_reader.shuffle is ignored: evaluation reads records in file order')
 
+    rank, world = shard if shard is not None else (0, 1)
+
     def generator():
+        index = 0
         for path in paths:
             for record in tfrecord.read_records(path):
-                yield decode_example(record)
+                if limit is not None and index >= limit:
+                    return
+                if index % world == rank:
+                    yield decode_example(record)
+                index += 1
     return generator()

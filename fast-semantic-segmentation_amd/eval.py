@@ -4,7 +4,9 @@ Same flags as the reference's eval.py:25-53 (--evaluate_all_from_checkpoint,
 --train_dir, --eval_dir, --config_path, --image_summaries, --verbose,
 --limit_gpu_mem) plus --dtype / --batch_size.  Launch one process per GPU with
 torch.distributed.run to shard the examples; the confusion matrix is all-reduced
-over RCCL.
+over RCCL.  Rank 0 writes <eval_dir>/eval_results.json: per checkpoint the mIoU and
+the int64 confusion matrix.  Rehearsal knobs for several ranks on one GPU:
+FSS_DIST_BACKEND=gloo FSS_DEVICE=0.
 """
 import argparse
 import functools
@@ -41,7 +43,7 @@ def main(argv=None):
     ap.add_argument('--image_summaries', action='store_true')
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--limit_gpu_mem', action='store_true')
-    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
+    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32', 'float32x3'])
     ap.add_argument('--batch_size', type=int, default=1)
     flags = ap.parse_args(argv)
 
@@ -52,9 +54,16 @@ def main(argv=None):
     from protos import pipeline_pb2
     from libs.evaluator import eval_segmentation_model, eval_segmentation_model_once
 
+    device = int(os.environ.get('FSS_DEVICE', os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(device)
     if 'WORLD_SIZE' in os.environ and int(os.environ['WORLD_SIZE']) > 1:
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
-        dist.init_process_group('nccl')
+        backend = os.environ.get('FSS_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device))
+        else:
+            dist.init_process_group(backend)
+    rank0 = not dist.is_initialized() or dist.get_rank() == 0
+    results = []
     os.makedirs(flags.eval_dir, exist_ok=True)
     if not os.path.isdir(flags.train_dir):
         raise ValueError('`train_dir` must be a valid directory containing model checkpoints '
@@ -76,22 +85,34 @@ def main(argv=None):
         input_dims, cropped_evaluation = (p.height, p.width), False
     else:
         raise ValueError('Must specify an `eval_input_type` for evaluation.')
-    extra = dict(dtype=flags.dtype, batch_size=flags.batch_size)
+    extra = dict(dtype=flags.dtype, batch_size=flags.batch_size, return_confusion=True)
     if flags.evaluate_all_from_checkpoint is not None:
         for curr_checkpoint in get_checkpoints_from_path(flags.evaluate_all_from_checkpoint,
                                                          flags.train_dir):
-            result = eval_segmentation_model_once(
+            result, cm = eval_segmentation_model_once(
                 curr_checkpoint, create_model_fn, create_input_fn, input_dims, eval_config,
                 eval_dir=flags.eval_dir, cropped_evaluation=cropped_evaluation,
                 image_summaries=flags.image_summaries, verbose=flags.verbose, **extra)
-            print('Evaluation of `{}` over. Eval values: {}'.format(curr_checkpoint, result))
+            results.append(dict(checkpoint=str(curr_checkpoint), mean_iou=float(result),
+                                confusion_matrix=cm.tolist()))
+            if rank0:
+                print('Evaluation of `{}` over. Eval values: {}'.format(curr_checkpoint, result))
     else:
-        result = eval_segmentation_model(
+        result, cm = eval_segmentation_model(
             create_model_fn, create_input_fn, input_dims, eval_config, train_dir=flags.train_dir,
             eval_dir=flags.eval_dir, cropped_evaluation=cropped_evaluation,
             evaluate_single_checkpoint=flags.evaluate_all_from_checkpoint,
             image_summaries=flags.image_summaries, verbose=flags.verbose, **extra)
-        print('Evaluation over. Eval values: {}'.format(result))
+        from fss import checkpoint
+        results.append(dict(checkpoint=str(checkpoint.latest_checkpoint(flags.train_dir)),
+                            mean_iou=float(result), confusion_matrix=cm.tolist()))
+        if rank0:
+            print('Evaluation over. Eval values: {}'.format(result))
+    if rank0:
+        import json
+        with open(os.path.join(flags.eval_dir, 'eval_results.json'), 'w') as f:
+            json.dump(dict(dtype=flags.dtype, world_size=dist.get_world_size() if dist.is_initialized() else 1,
+                           results=results), f)
     if dist.is_initialized():
         dist.destroy_process_group()
 

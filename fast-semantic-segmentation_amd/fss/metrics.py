@@ -55,9 +55,10 @@ class StreamingMeanIoU(object):
 
     def all_reduce(self):
         """Sums the confusion matrix over all ranks (RCCL when the process group
-        runs on GPUs, gloo in CPU tests).  No-op without a process group."""
+        runs on GPUs, gloo in CPU tests).  No-op without a process group; with one, the
+        collective runs even for a single rank (identity), so the path is the same at any size."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized():
             if dist.get_backend() == 'gloo':
                 t = self.cm.cpu()
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)

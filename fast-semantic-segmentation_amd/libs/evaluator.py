@@ -15,12 +15,22 @@ Same surface as the reference's libs/evaluator.py (`create_evaluation_input`
 Image and label are zero-padded to `input_dimensions` exactly as
 pad_to_specific_size does: padded label pixels are class 0 and do count.
 """
+import functools
+import inspect
 import itertools
 import logging
 
 import numpy as np
 
 from fss import graph as G
+
+
+def _accepts(fn, names):
+    try:
+        params = inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+    return all(n in params for n in names)
 
 
 def create_evaluation_input(create_input_dict_fn, input_height, input_width,
@@ -90,10 +100,19 @@ def eval_segmentation_model(create_model_fn, create_input_fn, input_dimensions, 
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(), dist.get_world_size()
 
-    examples = create_evaluation_input(create_input_fn, input_height, input_width,
-                                       cropped_evaluation)
-    examples = itertools.islice(examples, total_eval_examples)
-    mine = itertools.islice(examples, rank, None, world)
+    # example i (of the first num_examples) belongs to rank i % world.  An input function that
+    # takes `shard` / `limit` (dataset_builder.build) skips the other ranks' records before
+    # decoding them; any other iterable is decoded in full and sliced here.
+    expected = len(range(rank, total_eval_examples, world))
+    if _accepts(create_input_fn, ('shard', 'limit')):
+        mine = create_evaluation_input(
+            functools.partial(create_input_fn, shard=(rank, world), limit=total_eval_examples),
+            input_height, input_width, cropped_evaluation)
+    else:
+        examples = create_evaluation_input(create_input_fn, input_height, input_width,
+                                           cropped_evaluation)
+        examples = itertools.islice(examples, total_eval_examples)
+        mine = itertools.islice(examples, rank, None, world)
     first = next(mine, None)
 
     graph = G.reset_default_graph()
@@ -127,6 +146,10 @@ def eval_segmentation_model(create_model_fn, create_input_fn, input_dimensions, 
         if batch:       # ragged tail: pad the batch with all-ignore labels
             count += _eval_batch(cg, miou, pred_val, labels_dev, batch, ignore_label)
         cg.sync()
+    if count < expected:
+        # the reference's reader repeats the dataset; this one stops at its end
+        logging.warning('rank %d evaluated %d examples, eval_config.num_examples asked for %d of them: '
+                        'the input holds fewer records', rank, count, expected)
     miou.all_reduce()
     metric_results = miou.result()
     logging.info('Evaluation over. Eval values: %s', metric_results)

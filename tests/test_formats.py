@@ -106,6 +106,21 @@ def test_tfrecord_example_round_trip(tmp_path):
     for (gi, gl), (ei, el) in zip(got, expected):
         np.testing.assert_array_equal(gi, ei)
         np.testing.assert_array_equal(gl, el)
+    # record-level sharding: record i belongs to rank i % world; records of other ranks and
+    # records past `limit` are skipped before they are decoded
+    calls = []
+    real = dataset_builder.decode_example
+    dataset_builder.decode_example = lambda r: (calls.append(1), real(r))[1]
+    try:
+        r0 = list(dataset_builder.build(cfg, shard=(0, 2)))
+        r1 = list(dataset_builder.build(cfg, shard=(1, 2)))
+        assert len(r0) == 2 and len(r1) == 1 and len(calls) == 3
+        np.testing.assert_array_equal(r0[1][0], expected[2][0])
+        np.testing.assert_array_equal(r1[0][1], expected[1][1])
+        assert len(list(dataset_builder.build(cfg, shard=(0, 2), limit=2))) == 1
+        assert len(list(dataset_builder.build(cfg, limit=2))) == 2
+    finally:
+        dataset_builder.decode_example = real
     with pytest.raises(ValueError, match='At least one input path'):
         cfg2 = input_reader_pb2.InputReader()
         dataset_builder.build(cfg2)
