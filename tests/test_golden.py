@@ -1,0 +1,80 @@
+"""The numpy oracle (CPU) and the HIP path (GPU) against the committed golden fixtures
+tests/golden/*.npz, which come from a second, independent implementation of the reference's
+graphs (torch CPU ops in float64, tests/golden/make_golden.py): intermediate tensors of
+architectures/icnet_architecture.py:110-174 / architectures/pspnet_architecture.py:88-147
+(backbone endpoints, pyramid pooling module, cascade feature fusion, classifier scores) and the
+final label map, for ICNet-0.5 ResNet50, PSPNet-1.0 ResNet50 and ICNet-1.0 MobileNetV2."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import nets, ops as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURES = sorted(glob.glob(os.path.join(HERE, 'golden', '*.npz')))
+
+
+def _case(path):
+    d = np.load(path)
+    stem = os.path.basename(path)
+    arch = 'icnet' if stem.startswith('icnet') else 'pspnet'
+    ext = 'dilated_mobilenet' if 'mobilenet' in stem else 'dilated_resnet50'
+    return d, arch, ext, float(d['filter_scale']), [float(v) for v in d['pooling_factors']], \
+        tuple(int(v) for v in d['pad'])
+
+
+def _taps(d):
+    for k in d.files:
+        if k.startswith('tap/'):
+            name = k[4:]
+            yield name, d[k], int(d['tap_stride/' + name]) if 'tap_stride/' + name in d.files else 1
+
+
+def test_fixtures_present():
+    assert len(FIXTURES) == 3
+
+
+@pytest.mark.parametrize('path', FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_oracle_matches_the_second_implementation(path):
+    from test_models_gpu import build
+    d, arch, ext, fs, pf, pad = _case(path)
+    img = d['image']
+    g, cfg, outs, weights = build(arch, ext, fs, pf, (1,) + img.shape, pad)
+    x = nets.preprocess(O.pad_to_bounding_box(img[None].astype(np.float32), pad[0], pad[1]), ext)
+    fn = nets.icnet_predict if arch == 'icnet' else nets.pspnet_predict
+    logits, taps = fn(nets.Params(weights), x, filter_scale=1.0 / fs, pooling_factors=pf, extractor=ext,
+                      return_all=True)
+    seen = 0
+    for name, gold, step in _taps(d):
+        got = taps[name][:, ::step, ::step]
+        assert got.shape == gold.shape, name
+        err = float(np.abs(got - gold).max()) / max(float(np.abs(gold).max()), 1e-6)
+        assert err <= 2e-5, '%s: %.3g of scale' % (name, err)      # float32 oracle vs float64 torch
+        seen += 1
+    assert seen >= 3
+    labels = O.argmax_channels(logits)[0]
+    assert (labels == d['labels']).mean() >= 0.9999
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', ['float32', 'float32x3', 'bfloat16'])
+@pytest.mark.parametrize('path', FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_hip_path_matches_the_second_implementation(path, dtype):
+    from fss import plan
+    from test_models_gpu import build
+    d, arch, ext, fs, pf, pad = _case(path)
+    img = d['image']
+    g, cfg, outs, weights = build(arch, ext, fs, pf, (1,) + img.shape, pad)
+    logits, labels = plan.CompiledGraph(g, outs, weights, dtype=dtype).run(img)
+    low = d['tap/logits_lowres']
+    assert 'tap_stride/logits_lowres' not in d.files
+    gold = O.resize_bilinear(low, pad[0], pad[1], True)           # the model's final zoom
+    err = float(np.abs(logits - gold).max()) / float(np.abs(gold).max())
+    agree = float((labels[0, ..., 0] == d['labels']).mean())
+    print('%s %s: logit err %.3g of scale, labels agree %.5f' % (os.path.basename(path)[:-4], dtype, err, agree))
+    if dtype == 'bfloat16':
+        assert err <= 2e-2 and agree >= 0.97       # measured floor; bf16 does not meet the label gate
+    else:
+        assert err <= 1e-3 and agree >= 0.999
