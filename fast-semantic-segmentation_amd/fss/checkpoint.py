@@ -41,12 +41,65 @@ def _make_table():
 _CRC_TABLE = _make_table()
 
 
-def crc32c(data):
-    crc = 0xFFFFFFFF
+def _crc_bytes(state, data):
+    """Advances the raw CRC register `state` over `data`, one byte at a time."""
     tbl = _CRC_TABLE
     for b in bytes(data):
-        crc = int(tbl[(crc ^ b) & 0xFF]) ^ (crc >> 8)
-    return crc ^ 0xFFFFFFFF
+        state = int(tbl[(state ^ b) & 0xFF]) ^ (state >> 8)
+    return state
+
+
+def _gf2_apply(mat, vec):
+    """mat: 32 columns (uint32 each) of a GF(2) matrix; returns mat * vec."""
+    out, i = 0, 0
+    while vec:
+        if vec & 1:
+            out ^= mat[i]
+        vec >>= 1
+        i += 1
+    return out
+
+
+def _zero_advance_matrix(nbytes):
+    """The linear map that advancing the CRC register over `nbytes` zero bytes applies."""
+    mat = [_crc_bytes(1 << i, b'\x00') for i in range(32)]       # one zero byte
+    result = [1 << i for i in range(32)]                         # identity
+    while nbytes:
+        if nbytes & 1:
+            result = [_gf2_apply(mat, c) for c in result]
+        mat = [_gf2_apply(mat, c) for c in mat]
+        nbytes >>= 1
+    return result
+
+
+_CRC_BLOCK = 4096
+_CRC_ADVANCE = None
+
+
+def crc32c(data):
+    """CRC-32C (Castagnoli) of a bytes-like object.  Large inputs are cut into 4 KiB blocks
+    whose raw CRCs (register started at 0) are computed in lock step with numpy - one table
+    look-up per byte position for all blocks at once - and chained with the register's
+    zero-advance matrix: crc(A | B) = advance_len(B)(crc(A)) xor raw(B), the CRC being linear."""
+    global _CRC_ADVANCE
+    buf = np.frombuffer(bytes(data) if not isinstance(data, (bytes, bytearray, memoryview, np.ndarray))
+                        else data, dtype=np.uint8)
+    n = buf.size
+    if n < 4 * _CRC_BLOCK:
+        return _crc_bytes(0xFFFFFFFF, buf.tobytes()) ^ 0xFFFFFFFF
+    nblk = n // _CRC_BLOCK
+    blocks = buf[:nblk * _CRC_BLOCK].reshape(nblk, _CRC_BLOCK)
+    reg = np.zeros(nblk, np.uint32)
+    tbl = _CRC_TABLE
+    for col in range(_CRC_BLOCK):
+        reg = tbl[(reg ^ blocks[:, col]) & 0xFF] ^ (reg >> 8)
+    if _CRC_ADVANCE is None:
+        _CRC_ADVANCE = _zero_advance_matrix(_CRC_BLOCK)
+    state = 0xFFFFFFFF
+    for r in reg.tolist():
+        state = _gf2_apply(_CRC_ADVANCE, state) ^ r
+    state = _crc_bytes(state, buf[nblk * _CRC_BLOCK:].tobytes())
+    return state ^ 0xFFFFFFFF
 
 
 def masked_crc32c(data):
@@ -225,7 +278,7 @@ def load_variables(prefix, wanted=None, verify=True):
             path = '%s.data-%05d-of-%05d' % (prefix, sid, num_shards)
             shards[sid] = np.memmap(path, dtype=np.uint8, mode='r')
         raw = shards[sid][e['offset']:e['offset'] + e['size']]
-        if verify and e['crc32c'] is not None and e['size'] <= (1 << 16):
+        if verify and e['crc32c'] is not None:
             if masked_crc32c(raw.tobytes()) != e['crc32c']:
                 raise ValueError('checksum mismatch in variable %s' % name)
         arr = np.frombuffer(raw.tobytes(), dtype=_DTYPES[e['dtype']]).reshape(e['shape'])
@@ -271,7 +324,7 @@ def save_variables(prefix, variables, block_size=4096):
             f.write(raw)
             items.append((name.encode('utf-8'),
                           _encode_entry(_DTYPE_CODES[arr.dtype], arr.shape, 0, offset, len(raw),
-                                        masked_crc32c(raw) if len(raw) <= (1 << 16) else 0)))
+                                        masked_crc32c(raw))))
             offset += len(raw)
     header = b'\x08\x01' + b'\x1a\x02\x08\x01'     # num_shards=1, version{producer=1}
     items = [(b'', header)] + items

@@ -351,6 +351,13 @@ class CompiledGraph(object):
     # ---- convolutions
     def _fold_bn(self, a, cout):
         W = self.weights
+        if a['bn'] is not None and a['bn']['var'] not in W:
+            # weights from a frozen graph whose batch norm is already folded: the kernel is
+            # used as it is, with the constant vector the graph adds behind the convolution
+            key = a['weights'].rsplit('/', 1)[0] + '/folded_bias'
+            if key not in W:
+                raise KeyError('neither batch norm statistics nor a folded bias for %s' % a['weights'])
+            return np.ones(cout, np.float64), W[key].astype(np.float64)
         if a['bn'] is not None:
             bn = a['bn']
             scale = 1.0 / np.sqrt(W[bn['var']].astype(np.float64) + bn['epsilon'])

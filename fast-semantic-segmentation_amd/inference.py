@@ -39,12 +39,13 @@ def _get_images_from_path(input_path):
 def run_inference_graph(model, trained_checkpoint_prefix, input_images, input_shape, pad_to_shape,
                         label_color_map, output_directory, dtype='bfloat16'):
     from PIL import Image
-    from fss import checkpoint, graph as G
+    from fss import checkpoint, frozen_graph, graph as G
     from libs.exporter import deploy_segmentation_inference_graph, Session
     outputs, placeholder_tensor = deploy_segmentation_inference_graph(
         model=model, input_shape=input_shape, pad_to_shape=pad_to_shape,
         label_color_map=label_color_map)
-    weights = checkpoint.load_variables(trained_checkpoint_prefix, G.get_default_graph().variables)
+    # a checkpoint prefix, or the archive's frozen_inference_graph.pb
+    weights = frozen_graph.load_weights(trained_checkpoint_prefix, G.get_default_graph().variables)
     sess = Session(outputs, placeholder_tensor, weights, dtype=dtype)
     for idx, image_path in enumerate(input_images):
         image_raw = np.array(Image.open(image_path))

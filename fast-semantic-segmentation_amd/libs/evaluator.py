@@ -124,11 +124,11 @@ def eval_segmentation_model(create_model_fn, create_input_fn, input_dimensions, 
             segmentation_model, first[0].shape, input_height, input_width,
             cropped_evaluation, batch_size)
         if weights is None:
-            from fss import checkpoint
+            from fss import checkpoint, frozen_graph
             path = evaluate_single_checkpoint or checkpoint.latest_checkpoint(train_dir)
             if path is None:
                 raise ValueError('No checkpoints found in `train_dir`.')
-            weights = checkpoint.load_variables(path, graph.variables)
+            weights = frozen_graph.load_weights(path, graph.variables)
         cg = plan.CompiledGraph(graph, [predictions], weights, dtype=dtype)
         pred_val = cg.value(predictions)
         labels_dev = torch.zeros((batch_size, input_height, input_width), dtype=torch.uint8,

@@ -60,7 +60,10 @@ class Session(object):
         self._outputs = outputs if isinstance(outputs, (list, tuple)) else [outputs]
         self._single = not isinstance(outputs, (list, tuple))
         self.placeholder = placeholder
-        missing = [n for n in (graph or G.get_default_graph()).variables if n not in weights]
+        # batch norm statistics may be absent when the weights come from a frozen graph that
+        # has them folded into the kernels (then `<scope>/folded_bias` stands in for them)
+        missing = [n for n in (graph or G.get_default_graph()).variables if n not in weights
+                   and not ('/BatchNorm/' in n and n.split('/BatchNorm/')[0] + '/folded_bias' in weights)]
         if missing:
             raise KeyError('checkpoint is missing %d variables, e.g. %s'
                            % (len(missing), missing[:3]))

@@ -126,3 +126,76 @@ def test_tfrecord_example_round_trip(tmp_path):
         dataset_builder.build(cfg2)
     with pytest.raises(ValueError, match='not of type'):
         dataset_builder.build(object())
+
+
+def test_crc32c_known_answers_and_large_tensor_corruption(tmp_path):
+    """CRC-32C check values (RFC 3720 B.4), the blocked numpy form against the byte loop, and a
+    flipped byte in a LARGE tensor of a checkpoint (every tensor is checksummed)."""
+    assert checkpoint.crc32c(b'123456789') == 0xE3069283
+    assert checkpoint.crc32c(bytes(32)) == 0x8A9136AA
+    assert checkpoint.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 4095, 16384, 16385, 4096 * 37 + 11):
+        d = rng.integers(0, 256, n).astype(np.uint8).tobytes()
+        assert checkpoint.crc32c(d) == checkpoint._crc_bytes(0xFFFFFFFF, d) ^ 0xFFFFFFFF
+    big = rng.normal(0, 1, (3, 3, 64, 128)).astype(np.float32)          # 295 KB
+    prefix = str(tmp_path / 'model.ckpt')
+    checkpoint.save_variables(prefix, {'a/weights': big, 'b/biases': np.zeros(4, np.float32)})
+    np.testing.assert_array_equal(checkpoint.load_variables(prefix)['a/weights'], big)
+    path = prefix + '.data-00000-of-00001'
+    raw = bytearray(open(path, 'rb').read())
+    raw[200000] ^= 0x10
+    open(path, 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='checksum mismatch'):
+        checkpoint.load_variables(prefix)
+
+
+def test_frozen_graph_reader(tmp_path):
+    """GraphDef of constants (plain and batch-norm-folded form) -> the weights dict; the plan
+    compiler's folding of (weights, folded_bias) equals its folding of the batch norm."""
+    from fss import frozen_graph
+    rng = np.random.default_rng(3)
+    v = {
+        'A/Conv/weights': rng.normal(0, 1, (3, 3, 8, 16)).astype(np.float32),
+        'A/Conv/BatchNorm/gamma': rng.uniform(0.5, 1.5, 16).astype(np.float32),
+        'A/Conv/BatchNorm/beta': rng.normal(0, 1, 16).astype(np.float32),
+        'A/Conv/BatchNorm/moving_mean': rng.normal(0, 1, 16).astype(np.float32),
+        'A/Conv/BatchNorm/moving_variance': rng.uniform(0.5, 1.5, 16).astype(np.float32),
+        'A/Dil/weights': rng.normal(0, 1, (3, 3, 16, 8)).astype(np.float32),
+        'A/Dil/BatchNorm/gamma': rng.uniform(0.5, 1.5, 8).astype(np.float32),
+        'A/Dil/BatchNorm/beta': rng.normal(0, 1, 8).astype(np.float32),
+        'A/Dil/BatchNorm/moving_mean': rng.normal(0, 1, 8).astype(np.float32),
+        'A/Dil/BatchNorm/moving_variance': rng.uniform(0.5, 1.5, 8).astype(np.float32),
+        'Predictions/Conv/weights': rng.normal(0, 1, (1, 1, 8, 19)).astype(np.float32),
+        'Predictions/Conv/biases': rng.normal(0, 1, 19).astype(np.float32),
+        'global_step': np.asarray(7, np.int64),
+    }
+    convs = [('A/Conv', False), ('A/Dil', True), ('Predictions/Conv', False)]
+    plain = str(tmp_path / 'plain.pb')
+    frozen_graph.save_frozen_graph(plain, v, convs)
+    wanted = {k: a.shape for k, a in v.items() if k != 'global_step'}
+    got = frozen_graph.load_weights(plain, wanted)
+    assert set(got) == set(wanted)
+    for k in wanted:
+        np.testing.assert_array_equal(got[k], v[k])
+    assert 'global_step' not in frozen_graph.load_variables(plain)
+    with pytest.raises(KeyError, match='missing 1 variables'):
+        frozen_graph.load_variables(plain, ['A/Conv/weights', 'B/weights'])
+    with pytest.raises(ValueError, match='has shape'):
+        frozen_graph.load_variables(plain, {'A/Conv/weights': (1, 1, 8, 16)})
+    # node structure of the file: constants, their read ops and the convolutions
+    nodes = frozen_graph.parse_graph_def(open(plain, 'rb').read())
+    ops = {n['name']: n['op'] for n in nodes}
+    assert ops['A/Conv/weights'] == 'Const' and ops['A/Conv/weights/read'] == 'Identity'
+    assert ops['A/Dil/Conv2D'] == 'Conv2D'
+    # folded form: BatchNorm constants are gone, a bias is added behind the convolution
+    folded = str(tmp_path / 'folded.pb')
+    frozen_graph.save_frozen_graph(folded, v, convs, fold_batch_norm=True)
+    got = frozen_graph.load_weights(folded, wanted)
+    assert not any('BatchNorm' in k for k in got)
+    for scope in ('A/Conv', 'A/Dil'):
+        s = v[scope + '/BatchNorm/gamma'] / np.sqrt(v[scope + '/BatchNorm/moving_variance'].astype(np.float64) + 1e-5)
+        np.testing.assert_allclose(got[scope + '/weights'], v[scope + '/weights'] * s, rtol=1e-6)
+        np.testing.assert_allclose(got[scope + '/folded_bias'],
+                                   v[scope + '/BatchNorm/beta'] - v[scope + '/BatchNorm/moving_mean'] * s, rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(got['Predictions/Conv/biases'], v['Predictions/Conv/biases'])
