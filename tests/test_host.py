@@ -209,3 +209,60 @@ def test_confusion_allreduce_world_size_2_gloo():
                           '29611', script], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'DIST_OK' in out.stdout
+
+
+def test_filter_pruner_gives_the_half_width_model(tmp_path):
+    """compress.py on ICNet-1.0 / PSPNet-1.0 weights with the shipped prune configs and factor 0.5:
+    every pruned variable has the shape the filter_scale 0.5 model declares, the pruned ICNet has
+    the published 6.71 M convolution parameters (docs/model_zoo.md:28), and the kept filters of
+    a convolution are those with the largest L1 norms, in their original order
+    (libs/filter_pruner.py:163-177)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from google.protobuf import text_format
+    from protos import pipeline_pb2
+    from builders import model_builder
+    from fss import checkpoint, graph as G, synth
+    import compress
+
+    def model(arch, fs, pf):
+        cfg = ("model { %s { num_classes: 19 filter_scale: %s pooling_factors: %s "
+               "feature_extractor { type: 'dilated_resnet50' } "
+               "hyperparams { batch_norm { train: true scale: true center: true decay: 0.9997 epsilon: 0.00001 } "
+               "regularizer { l2_regularizer { weight: 0.0001 } } initializer { variance_scaling_initializer {} } } "
+               "loss { classification_loss { softmax {} } use_auxiliary_loss: true } } }" % (arch, fs, pf))
+        pc = pipeline_pb2.PipelineConfig()
+        text_format.Merge(cfg, pc)
+        g = G.reset_default_graph()
+        _, m = model_builder.build(pc.model, is_training=False)
+        m.predict(m.preprocess(G.to_float(G.placeholder((1, 129, 257, 3)))))
+        return cfg, dict(g.variables)
+
+    for arch, pf, prune, params in (('icnet', [1.0, 2.0, 3.0, 4.0], 'icnet_resnet_v1_pruner_v2', 6708032),
+                                    ('pspnet', [1.0, 2.0, 3.0, 6.0], 'pspnet50_resnet_v1_pruner', None)):
+        cfg_text, full_vars = model(arch, 1.0, pf)
+        _, half_vars = model(arch, 0.5, pf)
+        weights = synth.make_weights(full_vars)
+        d = tmp_path / arch
+        d.mkdir()
+        (d / 'pipeline.config').write_text(cfg_text)
+        checkpoint.save_variables(str(d / 'model.ckpt'), weights)
+        rc = compress.main(['--input_checkpoint', str(d / 'model.ckpt'), '--config_path', str(d / 'pipeline.config'),
+                            '--prune_config', os.path.join(PKG, 'configs', 'compression', prune + '.prune_config'),
+                            '--compression_factor', '0.5', '--output_dir', str(d / 'out')])
+        assert rc == 0
+        pruned = checkpoint.load_variables(str(d / 'out' / 'pruned_model.ckpt'), half_vars)
+        assert set(pruned) == set(half_vars)
+        if params:
+            assert sum(v.size for k, v in pruned.items() if k.endswith('/weights')) == params
+        # a convolution pruned by its own norms: the root convolution
+        name = 'SharedFeatureExtractor/resnet_v1_50/conv1/weights'
+        w = weights[name]
+        keep = np.sort(np.argsort(-np.abs(w).sum((0, 1, 2)))[:w.shape[3] // 2])
+        np.testing.assert_array_equal(pruned[name], w[..., keep])
+        np.testing.assert_array_equal(pruned[name.replace('weights', 'BatchNorm/gamma')],
+                                      weights[name.replace('weights', 'BatchNorm/gamma')][keep])
+        # ... and the next convolutions lost the same input channels
+        nxt = 'SharedFeatureExtractor/resnet_v1_50/block1/unit_1/bottleneck_v1/conv1/weights'
+        assert pruned[nxt].shape[2] == len(keep)
+    assert compress.main(['--input_checkpoint', str(tmp_path / 'nothing'), '--config_path', 'x',
+                          '--prune_config', 'y']) == -1

@@ -478,3 +478,28 @@ def test_side_chain_started_in_the_middle_of_the_pass():
     for round_ in range(3):                 # each capture destroys the previous executable
         cg._capture()
         check('two-stream graph %d' % round_)
+
+
+def test_pruned_weights_run_in_the_half_width_model():
+    """libs/filter_pruner on the ICNet-1.0 weights (factor 0.5, shipped prune config) gives weights
+    for the filter_scale 0.5 model - the path from a 1.0 checkpoint to the compressed model of
+    BASELINE's configuration 3: the HIP forward pass on them matches the oracle's."""
+    import os
+    from google.protobuf import text_format
+    from protos import compressor_pb2
+    from builders import compressor_builder
+    from conftest import PKG
+    from fss import plan
+    arch, ext, pf, in_shape, pad = 'icnet', 'dilated_resnet50', [1.0, 2.0, 3.0, 4.0], (1, 128, 256, 3), (129, 257)
+    g1, _, _, w1 = build(arch, ext, 1.0, pf, in_shape, pad)
+    c = compressor_pb2.CommpressionConfig()
+    with open(os.path.join(PKG, 'configs', 'compression', 'icnet_resnet_v1_pruner_v2.prune_config')) as f:
+        text_format.Merge(f.read(), c)
+    pruned = compressor_builder.build(c.compression_strategy, [], 0.5).compress(g1, w1)
+    g, cfg, outs, _ = build(arch, ext, 0.5, pf, in_shape, pad)
+    assert all(tuple(pruned[k].shape) == tuple(v) for k, v in g.variables.items())
+    img = np.random.default_rng(5).integers(0, 256, in_shape).astype(np.uint8)
+    ref = oracle_logits(arch, ext, 0.5, pf, img, pad, pruned)
+    logits, labels = plan.CompiledGraph(g, outs, pruned, dtype='float32').run(img)
+    assert float(np.abs(logits - ref).max()) <= 1e-3 * float(np.abs(ref).max())
+    assert (labels[..., 0] == O.argmax_channels(ref)).mean() >= 0.999
