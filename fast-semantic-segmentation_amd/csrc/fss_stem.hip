@@ -58,14 +58,21 @@ template <> struct StemPix<float> {
 // NJ = 16-channel groups of output channels (cout_pad = 16 * NJ); KS = MFMA k steps of the
 // filter when known at compile time (bf16: 7 for 7x7, 2 for 3x3; the tap walk is then
 // unrolled with its patch offsets in registers), 0 = any filter
-template <typename T, int NJ, int KS>
+// SPLIT (T = bf16_t, TO = float): the float-quality form.  The preprocessed patch is kept as two
+// bf16 images (high parts, remainders), the weights arrive as two bf16 matrices (high parts
+// [cout_pad][k_pad], then remainders), and every MFMA step runs three times (lo*hi, hi*lo,
+// hi*hi) into the same float accumulators; the output is float.
+template <typename T, int NJ, int KS, typename TO = T, bool SPLIT = false>
 __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   constexpr int ES = (int)sizeof(T);
+  static_assert(!SPLIT || (sizeof(T) == 2 && sizeof(TO) == 4), "split mode: bf16 operands, float output");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* tapoff = reinterpret_cast<int*>(smem);            // 64 patch offsets (in pixels)
   const int WROW = a.K4pad * ES + 16;                    // +16: rows land on distinct banks
   char* wl = smem + 256;
-  char* patch = wl + NJ * 16 * WROW;
+  char* patch = wl + (SPLIT ? 2 : 1) * NJ * 16 * WROW;
+  // split mode: remainders of the weights behind the high parts, of the patch behind the patch
+  const int WLO = NJ * 16 * WROW, PLO = a.PH * a.PW * 4 * ES;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -83,6 +90,9 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
       const int co = ((rho >> 2) & 3) * (4 * NJ) + 4 * (rho >> 4) + (rho & 3);
       *reinterpret_cast<uint4*>(wl + rho * WROW + c * 16) = *reinterpret_cast<const uint4*>(
           reinterpret_cast<const char*>(a.w) + ((size_t)co * a.K4pad * ES + c * 16));
+      if constexpr (SPLIT)
+        *reinterpret_cast<uint4*>(wl + WLO + rho * WROW + c * 16) = *reinterpret_cast<const uint4*>(
+            reinterpret_cast<const char*>(a.w) + ((size_t)(NJ * 16 + co) * a.K4pad * ES + c * 16));
     }
   }
   float bias[NJ][4];
@@ -96,7 +106,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   const float act_lo = a.act == FSS_ACT_NONE ? -INFINITY : 0.f;
   const float act_hi = a.act == FSS_ACT_RELU6 ? 6.f : INFINITY;
   // whole-lane vector stores need every lane's piece 16-byte aligned
-  const bool vec_ok = (a.y_ld * ES) % 16 == 0 && g * (4 * NJ) + 4 * NJ <= a.Cout;
+  const bool vec_ok = (a.y_ld * (int)sizeof(TO)) % 16 == 0 && g * (4 * NJ) + 4 * NJ <= a.Cout;
 
   // this wave's four 16-pixel groups: output rows 2*wave, 2*wave+1, columns 0-15 / 16-31.
   // base: patch pixel of tap (0,0) (clamped for columns past the tile, whose results are
@@ -175,6 +185,16 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
       u[k] = *reinterpret_cast<const unsigned*>(frame + off4) >> ((off - off4) * 8u);
     }
   };
+  // one preprocessed pixel into the patch (split mode: its bf16 high parts and remainders)
+  auto store_pix = [&](int pix, const float (&v)[3]) {
+    char* dst = patch + (size_t)pix * (4 * ES);
+    StemPix<T>::store(dst, v[0], v[1], v[2]);
+    if constexpr (SPLIT) {
+      const uint2 hi = *reinterpret_cast<const uint2*>(dst);
+      StemPix<T>::store(dst + PLO, v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u),
+                        v[2] - __uint_as_float(hi.y << 16));
+    }
+  };
   // zero padding of the frame, mean / scale, rounding; stores the patch into LDS
   auto commit = [&](const Tile& t, const unsigned (&u)[kStemRows]) {
     const int i0 = t.oh0 * a.stride - a.pad_t, j0 = t.ow0 * a.stride - a.pad_l;
@@ -189,7 +209,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
             v[c] = (float)((u[k] >> (8 * c)) & 255u) - a.mean[c];
             if (!a.unit_scale) v[c] *= a.scale[c];
           }
-          if (lane < a.PW) StemPix<T>::store(patch + (size_t)(pi * a.PW + lane) * (4 * ES), v[0], v[1], v[2]);
+          if (lane < a.PW) store_pix(pi * a.PW + lane, v);
         }
       }
       return;
@@ -210,7 +230,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
           if (!a.unit_scale) v[c] *= a.scale[c];
           v[c] = inside ? v[c] : 0.f;
         }
-        if (lane < a.PW) StemPix<T>::store(patch + (size_t)(pi * a.PW + lane) * (4 * ES), v[0], v[1], v[2]);
+        if (lane < a.PW) store_pix(pi * a.PW + lane, v);
       }
     }
   };
@@ -249,11 +269,29 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj)
           wa[nj] = *reinterpret_cast<const uint4*>(wl + (16 * nj + p) * WROW + (32 * st + 8 * g) * 2);
+        uint4 wlo[SPLIT ? NJ : 1];
+        if constexpr (SPLIT) {
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj)
+            wlo[nj] = *reinterpret_cast<const uint4*>(wl + WLO + (16 * nj + p) * WROW + (32 * st + 8 * g) * 2);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const uint2 b0 = *reinterpret_cast<const uint2*>(patch + (bo[mt] + to.x * 8));
           const uint2 b1 = *reinterpret_cast<const uint2*>(patch + (bo[mt] + to.y * 8));
           const uint4 b = make_uint4(b0.x, b0.y, b1.x, b1.y);
+          if constexpr (SPLIT) {
+            const uint2 c0 = *reinterpret_cast<const uint2*>(patch + PLO + (bo[mt] + to.x * 8));
+            const uint2 c1 = *reinterpret_cast<const uint2*>(patch + PLO + (bo[mt] + to.y * 8));
+            const uint4 bl = make_uint4(c0.x, c0.y, c1.x, c1.y);
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) {
+              acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8_t, wlo[nj]), __builtin_bit_cast(bf16x8_t, b), acc[mt][nj], 0, 0, 0);
+              acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8_t, wa[nj]), __builtin_bit_cast(bf16x8_t, bl), acc[mt][nj], 0, 0, 0);
+            }
+          }
 #pragma unroll
           for (int nj = 0; nj < NJ; ++nj)
             acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -268,11 +306,29 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj)
           wa[nj] = *reinterpret_cast<const uint4*>(wl + (16 * nj + p) * WROW + (32 * st + 8 * g) * 2);
+        uint4 wlo[SPLIT ? NJ : 1];
+        if constexpr (SPLIT) {
+#pragma unroll
+          for (int nj = 0; nj < NJ; ++nj)
+            wlo[nj] = *reinterpret_cast<const uint4*>(wl + WLO + (16 * nj + p) * WROW + (32 * st + 8 * g) * 2);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const uint2 b0 = *reinterpret_cast<const uint2*>(patch + (size_t)(base[mt] + to.x) * 8);
           const uint2 b1 = *reinterpret_cast<const uint2*>(patch + (size_t)(base[mt] + to.y) * 8);
           const uint4 b = make_uint4(b0.x, b0.y, b1.x, b1.y);
+          if constexpr (SPLIT) {
+            const uint2 c0 = *reinterpret_cast<const uint2*>(patch + PLO + (size_t)(base[mt] + to.x) * 8);
+            const uint2 c1 = *reinterpret_cast<const uint2*>(patch + PLO + (size_t)(base[mt] + to.y) * 8);
+            const uint4 bl = make_uint4(c0.x, c0.y, c1.x, c1.y);
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) {
+              acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8_t, wlo[nj]), __builtin_bit_cast(bf16x8_t, b), acc[mt][nj], 0, 0, 0);
+              acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8_t, wa[nj]), __builtin_bit_cast(bf16x8_t, bl), acc[mt][nj], 0, 0, 0);
+            }
+          }
 #pragma unroll
           for (int nj = 0; nj < NJ; ++nj)
             acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -298,13 +354,13 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
     }
 
     // lane (p, g) holds channels g*4*NJ .. +4*NJ-1 of pixel p of each group
-    T* __restrict__ ytile = reinterpret_cast<T*>(a.y) +
+    TO* __restrict__ ytile = reinterpret_cast<TO*>(a.y) +
                             (((size_t)now.n * a.Ho + now.oh0) * a.Wo + now.ow0) * a.y_ld;
     const int rows_left = a.Ho - now.oh0, cols_left = min(a.TW, a.Wo - now.ow0);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if (2 * wave + (mt >> 1) >= rows_left || (mt & 1) * 16 + p >= cols_left) continue;
-      T* dst = ytile + ooff[mt];
+      TO* dst = ytile + ooff[mt];
       float v[4 * NJ];
 #pragma unroll
       for (int nj = 0; nj < NJ; ++nj)
@@ -312,7 +368,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
         for (int q = 0; q < 4; ++q)
           v[4 * nj + q] = __builtin_amdgcn_fmed3f(acc[mt][nj][q] + bias[nj][q], act_lo, act_hi);   // clamp
       if (vec_ok) {
-        if constexpr (sizeof(T) == 4) {
+        if constexpr (sizeof(TO) == 4) {
 #pragma unroll
           for (int nj = 0; nj < NJ; ++nj)
             *reinterpret_cast<float4*>(dst + 4 * nj) =
@@ -335,15 +391,15 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
       } else {
 #pragma unroll
         for (int e = 0; e < 4 * NJ; ++e)
-          if (g * (4 * NJ) + e < a.Cout) ElemTraits<T>::store(dst + e, v[e]);
+          if (g * (4 * NJ) + e < a.Cout) ElemTraits<TO>::store(dst + e, v[e]);
       }
     }
   }
 }
 
-template <typename T, int NJ, int KS = 0>
+template <typename T, int NJ, int KS = 0, typename TO = T, bool SPLIT = false>
 static int launch_stem(const StemArgs& a, size_t smem, hipStream_t stream) {
-  auto kern = stem_conv_kernel<T, NJ, KS>;
+  auto kern = stem_conv_kernel<T, NJ, KS, TO, SPLIT>;
   if (smem > 64 * 1024) {
     static size_t attr_bytes = 0;   // per instantiation
     if (smem > attr_bytes) {
@@ -386,10 +442,10 @@ using namespace fss;
 
 extern "C" int fss_stem_pack_dims(int kh, int kw, int cout, int dtype, int* k_pad, int* cout_pad) {
   FSS_REQUIRE(k_pad && cout_pad, "null argument");
-  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16, "bad dtype");
+  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F32_BF16X3, "bad dtype");
   FSS_REQUIRE(kh > 0 && kw > 0 && kh * kw <= 64 && cout > 0 && cout <= 64, "bad shape");
   const int k4 = kh * kw * 4;
-  *k_pad = dtype == FSS_BF16 ? (k4 + 31) / 32 * 32 : k4;
+  *k_pad = dtype != FSS_F32 ? (k4 + 31) / 32 * 32 : k4;
   *cout_pad = (cout + 15) / 16 * 16;
   return 0;
 }
@@ -400,7 +456,7 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
                                 int dilation, int pad_top, int pad_left, int ho, int wo, int act,
                                 int dtype, int y_ld, void* stream) {
   FSS_REQUIRE(x && w_packed && y && mean3 && scale3, "null argument");
-  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16, "bad dtype");
+  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F32_BF16X3, "bad dtype");
   FSS_REQUIRE(n > 0 && hr > 0 && wr > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "bad shape");
   FSS_REQUIRE(sub >= 1 && sub <= 8, "sub must be in [1, 8]");
   FSS_REQUIRE(kh > 0 && kw > 0 && kh * kw <= 64, "filter must have at most 64 taps");
@@ -438,8 +494,8 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
   a.total_tiles = (int)total;
   for (int i = 0; i < 3; ++i) { a.mean[i] = mean3[i]; a.scale[i] = scale3[i]; }
   a.unit_scale = scale3[0] == 1.f && scale3[1] == 1.f && scale3[2] == 1.f;
-  const int es = dtype == FSS_F32 ? 4 : 2;
-  const size_t smem = 256 + (size_t)cout_pad * (k_pad * es + 16) + (size_t)a.PH * a.PW * 4 * es;
+  const int es = dtype == FSS_F32 ? 4 : 2, planes = dtype == FSS_F32_BF16X3 ? 2 : 1;
+  const size_t smem = 256 + planes * ((size_t)cout_pad * (k_pad * es + 16) + (size_t)a.PH * a.PW * 4 * es);
   FSS_REQUIRE(smem <= 160 * 1024, "filter too large for LDS");
   hipStream_t s = (hipStream_t)stream;
   const int nj = cout_pad / 16;
@@ -451,6 +507,17 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
     default: return launch_stem<T, 4>(a, smem, s);               \
   }
   if (dtype == FSS_F32) { FSS_STEM(float) }
+  if (dtype == FSS_F32_BF16X3) {
+    if (nj == 4 && k_pad == 224) return launch_stem<bf16_t, 4, 7, float, true>(a, smem, s);
+    if (nj == 2 && k_pad == 64) return launch_stem<bf16_t, 2, 2, float, true>(a, smem, s);
+    if (nj == 4 && k_pad == 64) return launch_stem<bf16_t, 4, 2, float, true>(a, smem, s);
+    switch (nj) {
+      case 1: return launch_stem<bf16_t, 1, 0, float, true>(a, smem, s);
+      case 2: return launch_stem<bf16_t, 2, 0, float, true>(a, smem, s);
+      case 3: return launch_stem<bf16_t, 3, 0, float, true>(a, smem, s);
+      default: return launch_stem<bf16_t, 4, 0, float, true>(a, smem, s);
+    }
+  }
   // the two filters of the reference's networks: unrolled tap walk
   if (nj == 4 && k_pad == 224) return launch_stem<bf16_t, 4, 7>(a, smem, s);
   if (nj == 2 && k_pad == 64) return launch_stem<bf16_t, 2, 2>(a, smem, s);

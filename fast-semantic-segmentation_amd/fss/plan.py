@@ -404,12 +404,18 @@ class CompiledGraph(object):
         Wt = self.weights[a['weights']].astype(np.float64) * scale      # [kh,kw,3,cout]
         Wt = np.pad(Wt, ((0, 0), (0, 0), (0, 1), (0, 0)))
         k_pad, cout_pad = ctypes.c_int(0), ctypes.c_int(0)
-        _lib.call('fss_stem_pack_dims', kh, kw, cout, _CODE[self.dt], ctypes.byref(k_pad),
+        code = self._in_code(self.dt)
+        _lib.call('fss_stem_pack_dims', kh, kw, cout, code, ctypes.byref(k_pad),
                   ctypes.byref(cout_pad))
         Wp = np.zeros((cout_pad.value, k_pad.value), np.float32)
         Wp[:cout, :kh * kw * 4] = Wt.transpose(3, 0, 1, 2).reshape(cout, -1)
         if self.dt == 'bf16':
             wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+        elif self.split:
+            # two bf16 matrices: high parts, then remainders
+            hi = f32_to_bf16_bits(Wp)
+            lo = f32_to_bf16_bits(Wp - (hi.astype(np.uint32) << 16).view(np.float32))
+            wdev = torch.from_numpy(np.concatenate([hi, lo]).view(np.int16)).to(self.device)
         else:
             wdev = torch.from_numpy(Wp).to(self.device)
         self.keepalive.append(wdev)
@@ -425,7 +431,7 @@ class CompiledGraph(object):
         self._emit('stem', a['weights'].rsplit('/', 1)[0], 'fss_stem_conv_u8',
                    (x.ptr, wdev.data_ptr(), bdev.data_ptr(), out.ptr, n, hr, wr, sub, h, w, mean, sc,
                     cout, kh, kw, a['stride'], a['rate'], a['pad_top'], a['pad_left'], ho, wo,
-                    _lib.ACT_CODES[a['activation']], _CODE[self.dt], out.ld, self.sh),
+                    _lib.ACT_CODES[a['activation']], code, out.ld, self.sh),
                    flops=2 * n * ho * wo * cout * kh * kw * 3,
                    nbytes=n * (hr // sub) * (wr // sub) * 3 + n * ho * wo * cout * _ESZ[self.dt],
                    keep=(mean, sc))

@@ -29,7 +29,7 @@ extern "C" {
 
 #define FSS_F32 0
 #define FSS_BF16 1
-/* fss_conv_desc.in_dtype only: float tensors exactly as FSS_F32, but every product is formed on
+/* fss_conv_desc.in_dtype and the dtype of fss_stem_conv_u8 only: float tensors exactly as FSS_F32, but every product is formed on
  * the bf16 matrix pipe from a two-way bf16 split of both operands (a_hi*b_hi + a_hi*b_lo +
  * a_lo*b_hi with hi = bf16(v), lo = bf16(v - hi), float accumulation): about 16 mantissa bits
  * per operand, i.e. results of float quality (well inside 1e-3 of the logit scale) at several
@@ -287,7 +287,10 @@ int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho,
  * architectures/icnet_architecture.py:153-160 'Conv',
  * third_party/mobilenet_v2.py first conv).  Weights: [cout_pad][k_pad] with
  * k = (r*kw + s)*4 + ch (ch 3 = 0), dims from fss_stem_pack_dims, batch norm
- * folded in.  Limits: cout <= 64, kh*kw <= 64, stride, dilation <= 4. */
+ * folded in.  dtype FSS_F32_BF16X3: float output of float quality from three bf16 MFMAs per
+ * step; the packed weights are two bf16 matrices [cout_pad][k_pad], the high parts bf16(W)
+ * followed by the remainders bf16(W - high), dims from fss_stem_pack_dims with that dtype.
+ * Limits: cout <= 64, kh*kw <= 64, stride, dilation <= 4. */
 int fss_stem_pack_dims(int kh, int kw, int cout, int dtype, int* k_pad, int* cout_pad);
 int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const float* bias, void* y,
                      int n, int hr, int wr, int sub, int h, int w,

@@ -195,12 +195,16 @@ def pack_stem_weights(w, dt):
     kh, kw, cin, cout = w.shape
     assert cin == 3
     k_pad, cout_pad = ctypes.c_int(0), ctypes.c_int(0)
-    _lib.call('fss_stem_pack_dims', kh, kw, cout, DT[dt][0], ctypes.byref(k_pad), ctypes.byref(cout_pad))
+    _lib.call('fss_stem_pack_dims', kh, kw, cout, conv_in_code(dt), ctypes.byref(k_pad), ctypes.byref(cout_pad))
     wp = np.zeros((cout_pad.value, k_pad.value), np.float32)
     w4 = np.pad(w, ((0, 0), (0, 0), (0, 1), (0, 0)))
     wp[:cout, :kh * kw * 4] = w4.transpose(3, 0, 1, 2).reshape(cout, -1)
     if dt == 'bf16':
         return torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
+    if dt == 'f32x3':       # high parts, then remainders
+        hi = f32_to_bf16_bits(wp)
+        lo = f32_to_bf16_bits(wp - (hi.astype(np.uint32) << 16).view(np.float32))
+        return torch.from_numpy(np.concatenate([hi, lo]).view(np.int16)).cuda()
     return torch.from_numpy(wp).cuda()
 
 
@@ -220,7 +224,7 @@ def stem_conv(frames, w, bias, mean, scale, sub, logical_hw, stride, rate, pads,
     torch.cuda.synchronize()
     _lib.call('fss_stem_conv_u8', xd.data_ptr(), wdev.data_ptr(), bd.data_ptr(), y.data_ptr(),
               n, hr, wr, sub, logical_hw[0], logical_hw[1], m3, s3, cout, kh, kw, stride, rate,
-              pads[0], pads[1], ho, wo, _lib.ACT_CODES[act], DT[dt][0], ld, None)
+              pads[0], pads[1], ho, wo, _lib.ACT_CODES[act], conv_in_code(dt), ld, None)
     _lib.call('fss_device_sync')
     out = to_host(y)
     if ld != cout:
