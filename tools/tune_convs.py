@@ -28,9 +28,9 @@ def main():
         plan.CompiledGraph._TUNE_CACHE = {}
     jobs = []
     for name, (cfg_file, in_shape, pad_shape, batches) in CASES.items():
-        for dtype, edges in (('bfloat16', (16, 32)), ('float32', (32, 16))):
+        for dtype, edges in (('bfloat16', (16, 32)), ('float32', (32, 16)), ('float32x3', (32,))):
             for b in batches:
-                if dtype == 'float32' and name not in ('icnet10',):
+                if dtype == 'float32' and name not in ('icnet10',):      # float32x3: every model
                     continue
                 for e in edges:
                     jobs.append((name, cfg_file, in_shape, pad_shape, b, dtype, e))
