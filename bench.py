@@ -51,7 +51,7 @@ def measured_conv_traffic(batch, n_conv, dtype):
     return per_frame * batch / n_conv
 
 
-def build_plan(batch, dtype, with_labels=True, config=CONFIG):
+def build_plan(batch, dtype, with_labels=True, config=CONFIG, streams=2):
     from google.protobuf import text_format
     from protos import pipeline_pb2
     from builders import model_builder
@@ -65,7 +65,7 @@ def build_plan(batch, dtype, with_labels=True, config=CONFIG):
     predictions, placeholder = evaluator.create_predictions_and_labels(
         model, INPUT_SHAPE, PAD_SHAPE[0], PAD_SHAPE[1], False, batch)
     weights = synth.make_weights(g.variables, seed=1234)
-    cg = plan.CompiledGraph(g, [predictions], weights, dtype=dtype)
+    cg = plan.CompiledGraph(g, [predictions], weights, dtype=dtype, streams=streams)
     return cg, predictions, num_classes, weights
 
 
@@ -177,6 +177,7 @@ def main():
     ap.add_argument('--no-conformant', action='store_true',
                     help='skip the float32x3 (all tolerances met) figure and the parity figures')
     ap.add_argument('--no-host-fed', action='store_true')
+    ap.add_argument('--streams', type=int, default=2, help='1: single-stream graph (profiling)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-latency', action='store_true')
     args = ap.parse_args()
@@ -203,7 +204,7 @@ def main():
 
     from fss import metrics
     B = args.batch
-    cg, predictions, num_classes, weights = build_plan(B, args.dtype)
+    cg, predictions, num_classes, weights = build_plan(B, args.dtype, streams=args.streams)
     pred_val = cg.value(predictions)
     miou = metrics.StreamingMeanIoU(num_classes, 255)
 
