@@ -62,6 +62,9 @@ struct ConvArgs {
   int N, H, W, Cin, Cout, KH, KW, stride, dil, pad_t, pad_l, Ho, Wo, act;
   int Cin2;         // channels of x2: its K segment follows the filter taps in the packed weights
   int M, K, Kpad, y_ld, res_ld, tiles_m, tiles_n;
+  // split-K launches: the grid holds `splits` blocks per output tile, block z of a tile walks
+  // its share of the tile's K tiles and stores raw sums into slab z of y ([splits][M][y_ld])
+  int splits;
   // classifier head (HEAD kernels only): logits = act(conv) * w_head^T + bias_head
   const void* w_head;       // bf16 [32][Cout], rows >= cout_head zero
   const float* bias_head;   // [cout_head]
@@ -244,7 +247,9 @@ conv_igemm_kernel(const ConvArgs a) {
   // each XCD a contiguous range of tiles; n-tiles of one m-tile are adjacent.
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
-  const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int wg_all = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int zsplit = wg_all / (a.tiles_m * a.tiles_n);       // 0 unless this is a split-K launch
+  const int wg = wg_all - zsplit * (a.tiles_m * a.tiles_n);
   const int tile_n = wg % a.tiles_n, tile_m = wg / a.tiles_n;
 
   const int tid = threadIdx.x;
@@ -348,44 +353,14 @@ conv_igemm_kernel(const ConvArgs a) {
     }
   }
 
-  // issues the LOADS DMA pieces of K tile `kt` into ring slot `slot`; tiles past
-  // KT fetch zeros so every wave always has the same number of pieces in flight
-  auto issue = [&](int kt, int slot) {
-    const unsigned dstA = smem_base + slot * STAGE_BYTES + wave * 1024;
-    const unsigned dstB = dstA + BM * BKB;
-    if constexpr (ALIGNED) {
-      const int tbit = min(tap, 63);                    // bit 63 is never set
-      // byte offset of the tap inside one image: fits 32 bits (checked by the host)
-      const int tap_off = ((kr * a.dil * a.W + ks * a.dil) * a.Cin + kc) * (int)sizeof(T);
-      const bool second = a.Cin2 > 0 && tap == a.KH * a.KW;          // uniform
-      const unsigned off2 = r2off0 + (unsigned)(kc * (int)sizeof(T));
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        const bool ok = (tapmask[i] >> tbit) & 1ull;
-        const char* real = second ? x2c + (off2 + i * r2step) : rptr[i] + tap_off;
-        const void* src = ok ? (const void*)real : zero_src;
-        glds16(src, dstA + i * (NT * 16));
-      }
-    } else {
-      const int dr = kr * a.dil, ds = ks * a.dil;
-      const bool k_ok = kr < a.KH;
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) {
-        const int ih = ih0[i] + dr, iw = iw0[i] + ds;
-        const bool ok = k_ok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
-        const int off = ((dr * a.W + ds) * a.Cin + (kc - chunk * EPC)) * (int)sizeof(T);
-        const void* src = ok ? (const void*)(rptr[i] + off) : zero_src;
-        glds16(src, dstA + i * (NT * 16));
-      }
-    }
-    const bool w_ok = kt < KT;
-    // k index of the tile in the packed weights
-    const size_t wk = ALIGNED ? (size_t)(tap * a.Cin + kc) * sizeof(T) : (size_t)kt * BKB;
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const void* src = w_ok ? (const void*)(wptr[i] + wk) : zero_src;
-      glds16(src, dstB + i * (NT * 16));
-    }
+  // the block's share of its K tiles: all of them, or slice zsplit of a split-K launch
+  int kt0 = 0, kt1 = KT;
+  if (a.splits > 1) {
+    kt0 = (int)((long long)KT * zsplit / a.splits);
+    kt1 = (int)((long long)KT * (zsplit + 1) / a.splits);
+  }
+  // moves the tap walk one K tile on
+  auto advance = [&]() {
     kc += BK;
     if constexpr (ALIGNED) {
       const int ntaps_all = a.KH * a.KW + (a.Cin2 > 0 ? 1 : 0);
@@ -402,6 +377,48 @@ conv_igemm_kernel(const ConvArgs a) {
         if (++ks == a.KW) { ks = 0; ++kr; }
       }
     }
+  };
+  for (int t = 0; t < kt0; ++t) advance();
+  // issues the LOADS DMA pieces of K tile `kt` into ring slot `slot`; tiles past
+  // the block's last one fetch zeros so every wave always has the same number of pieces in flight
+  auto issue = [&](int kt, int slot) {
+    const bool in_range = kt < kt1;
+    const unsigned dstA = smem_base + slot * STAGE_BYTES + wave * 1024;
+    const unsigned dstB = dstA + BM * BKB;
+    if constexpr (ALIGNED) {
+      const int tbit = min(tap, 63);                    // bit 63 is never set
+      // byte offset of the tap inside one image: fits 32 bits (checked by the host)
+      const int tap_off = ((kr * a.dil * a.W + ks * a.dil) * a.Cin + kc) * (int)sizeof(T);
+      const bool second = a.Cin2 > 0 && tap == a.KH * a.KW;          // uniform
+      const unsigned off2 = r2off0 + (unsigned)(kc * (int)sizeof(T));
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const bool ok = in_range && ((tapmask[i] >> tbit) & 1ull);
+        const char* real = second ? x2c + (off2 + i * r2step) : rptr[i] + tap_off;
+        const void* src = ok ? (const void*)real : zero_src;
+        glds16(src, dstA + i * (NT * 16));
+      }
+    } else {
+      const int dr = kr * a.dil, ds = ks * a.dil;
+      const bool k_ok = in_range && kr < a.KH;
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) {
+        const int ih = ih0[i] + dr, iw = iw0[i] + ds;
+        const bool ok = k_ok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
+        const int off = ((dr * a.W + ds) * a.Cin + (kc - chunk * EPC)) * (int)sizeof(T);
+        const void* src = ok ? (const void*)(rptr[i] + off) : zero_src;
+        glds16(src, dstA + i * (NT * 16));
+      }
+    }
+    const bool w_ok = in_range;
+    // k index of the tile in the packed weights
+    const size_t wk = ALIGNED ? (size_t)(tap * a.Cin + kc) * sizeof(T) : (size_t)kt * BKB;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      const void* src = w_ok ? (const void*)(wptr[i] + wk) : zero_src;
+      glds16(src, dstB + i * (NT * 16));
+    }
+    advance();
   };
 
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -432,7 +449,7 @@ conv_igemm_kernel(const ConvArgs a) {
   constexpr int PASSES = SLABR * QPR / 64;   // pieces per lane per slab
   static_assert(SLABR * QPR % 64 == 0, "slab must split evenly over the lanes");
   constexpr int SLABS = WTM / SLABR;
-  TO* __restrict__ yg = reinterpret_cast<TO*>(a.y);
+  TO* __restrict__ yg = reinterpret_cast<TO*>(a.y) + (size_t)zsplit * a.M * a.y_ld;
   const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
   const int n_base = tile_n * BN + wn * WTN;
   const bool vec_ok = ((a.y_ld & (VW - 1)) == 0) && ((a.Cout & (VW - 1)) == 0) &&
@@ -440,10 +457,10 @@ conv_igemm_kernel(const ConvArgs a) {
                       (rg == nullptr ||
                        (((a.res_ld & (VW - 1)) == 0) && ((reinterpret_cast<uintptr_t>(a.res) & 15) == 0)));
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
+  for (int s = 0; s < NSTAGE - 1; ++s) issue(kt0 + s, s);
 
   int slot = 0, fill = NSTAGE - 1;
-  for (int kt = 0; kt < KT; ++kt) {
+  for (int kt = kt0; kt < kt1; ++kt) {
     wait_vmcnt<(NSTAGE - 2) * LOADS>();      // this wave's pieces of tile kt have landed
     __builtin_amdgcn_s_barrier();            // ... and everybody else's; slot `fill` is free
     issue(kt + NSTAGE - 1, fill);
@@ -725,7 +742,7 @@ static int launch_conv_impl(ConvArgs& a, hipStream_t stream) {
   constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BKB;
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cout, BN);
-  const long long blocks = (long long)a.tiles_m * a.tiles_n;
+  const long long blocks = (long long)a.tiles_m * a.tiles_n * a.splits;
   if (blocks <= 0 || blocks > 0x7fffffffLL) {
     set_error("fss_conv2d_nhwc: grid out of range");
     return 2;
@@ -950,6 +967,7 @@ static int conv_setup(const fss_conv_desc* d, const void* x, const void* x2, int
   a.K = k;
   a.Kpad = k_pad; a.y_ld = d->y_ld; a.res_ld = d->res_ld;
   a.tiles_m = a.tiles_n = 0;
+  a.splits = 1;
   a.w_head = nullptr; a.bias_head = nullptr; a.cout_head = 0;
   a.zy = a.zytb = a.zylr = a.zycn = nullptr; a.zH = a.zW = 0;
   FSS_REQUIRE(d->config >= 0 && d->config <= kNumConvConfigs, "config out of range");
@@ -1002,6 +1020,74 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
   a.y = y_head; a.y_ld = y_head_ld;
   a.w_head = w_head; a.bias_head = bias_head; a.cout_head = cout_head;
   return dispatch_conv_head(a, d->config, (hipStream_t)stream);
+}
+
+// Second launch of the split-K form: y = act(sum over slabs + bias + residual), 4 channels a thread,
+// slabs added in index order (the result does not depend on which block finished first).
+template <typename TR, typename TO>
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float* __restrict__ ws, int splits, int M, int ld, int cout,
+                     const float* __restrict__ bias, const TR* __restrict__ res, int res_ld,
+                     TO* __restrict__ y, int y_ld, int act) {
+  const int quads = ld >> 2;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long long)M * quads) return;
+  const int m = (int)(t / quads), n = (int)(t - (long long)m * quads) * 4;
+  if (n >= cout) return;
+  const size_t slab = (size_t)M * ld;
+  const float* p = ws + (size_t)m * ld + n;
+  float4 v = *reinterpret_cast<const float4*>(p);
+  for (int z = 1; z < splits; ++z) {
+    const float4 u = *reinterpret_cast<const float4*>(p + z * slab);
+    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+  }
+  float o[4] = {v.x, v.y, v.z, v.w};
+  const float lo = act == FSS_ACT_NONE ? -INFINITY : 0.f, hi = act == FSS_ACT_RELU6 ? 6.f : INFINITY;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (n + e < cout) {
+      float r = o[e] + (bias != nullptr ? bias[n + e] : 0.f);
+      if (res != nullptr) r += ElemTraits<TR>::load(res + (size_t)m * res_ld + n + e);
+      ElemTraits<TO>::store(y + (size_t)m * y_ld + n + e, fminf(fmaxf(r, lo), hi));
+    }
+  }
+}
+
+extern "C" int fss_conv2d_splitk_nhwc(const fss_conv_desc* d, const void* x, const void* w_packed,
+                                      const float* bias, const void* residual, void* y, int splits,
+                                      float* workspace, size_t workspace_bytes, void* stream) {
+  FSS_REQUIRE(splits >= 2 && splits <= 16, "splits must be 2..16");
+  FSS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "null or unaligned workspace");
+  ConvArgs a;
+  if (int rc = conv_setup(d, x, nullptr, 0, w_packed, bias, residual, y, a)) return rc;
+  const int ld = (d->cout + 3) / 4 * 4;
+  FSS_REQUIRE((size_t)splits * a.M * ld * sizeof(float) <= workspace_bytes,
+              "workspace too small: splits * n * ho * wo * round_up(cout, 4) floats");
+  a.bias = nullptr; a.res = nullptr; a.act = FSS_ACT_NONE;
+  a.y = workspace; a.y_ld = ld; a.splits = splits;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (d->in_dtype == FSS_F32) rc = dispatch_conv<float, float>(a, d->config, s);
+  else if (d->in_dtype == FSS_F32_BF16X3) rc = dispatch_conv<f32s_t, float>(a, d->config, s);
+  else rc = dispatch_conv<bf16_t, float>(a, d->config, s);
+  if (rc) return rc;
+  const long long threads = (long long)a.M * (ld / 4);
+  const unsigned blocks = (unsigned)((threads + 255) / 256);
+  if (d->in_dtype == FSS_BF16 && d->out_dtype == FSS_BF16)
+    hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, workspace, splits,
+                       a.M, ld, d->cout, bias, (const bf16_t*)residual, d->res_ld, (bf16_t*)y, d->y_ld, d->act);
+  else if (d->in_dtype == FSS_BF16)
+    hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, s, workspace, splits,
+                       a.M, ld, d->cout, bias, (const bf16_t*)residual, d->res_ld, (float*)y, d->y_ld, d->act);
+  else
+    hipLaunchKernelGGL((splitk_reduce_kernel<float, float>), dim3(blocks), dim3(256), 0, s, workspace, splits,
+                       a.M, ld, d->cout, bias, (const float*)residual, d->res_ld, (float*)y, d->y_ld, d->act);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(std::string("splitk_reduce launch: ") + hipGetErrorString(e));
+    return 3;
+  }
+  return 0;
 }
 
 extern "C" int fss_conv2d_nhwc(const fss_conv_desc* d, const void* x, const void* w_packed,

@@ -60,6 +60,8 @@ PROTOTYPES = {
     'fss_conv_config_info': (c_int, [c_int, c_int_p]),
     'fss_conv2d_nhwc': (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    'fss_conv2d_splitk_nhwc': (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     'fss_conv2d_dual_nhwc': (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     'fss_conv2d_dual_head_nhwc': (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p, c_int, c_void_p,

@@ -110,7 +110,8 @@ class Step(object):
 # index of the output-pointer arguments of every kernel entry point (everything else
 # that points into an activation buffer is read)
 _OUT_ARGS = {
-    'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,), 'fss_conv2d_dual_nhwc': (7,),
+    'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,), 'fss_conv2d_splitk_nhwc': (5, 7),
+    'fss_conv2d_dual_nhwc': (7,),
     'fss_conv2d_dual_head_nhwc': (13,), 'fss_zoom2_border_gather': (1, 2, 3), 'fss_zoom2_conv_commute': (4,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
     'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1, 7), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
@@ -129,7 +130,8 @@ class CompiledGraph(object):
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
                  fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True,
-                 fuse_head=True, collapse_zooms=True, commute_zoom=None, fuse_zoom_residual=None):
+                 fuse_head=True, collapse_zooms=True, commute_zoom=None, fuse_zoom_residual=None,
+                 ksplit=False):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         # 'float32x3': float32 tensors everywhere; the convolutions form their products on the
@@ -157,6 +159,10 @@ class CompiledGraph(object):
         if self.mfma_edge not in (16, 32):
             raise ValueError('mfma_edge must be 16 or 32')
         self.fuse_stem = fuse_stem
+        # split-K launches for convolutions with few output tiles and a long K axis (one or two
+        # frames per launch): lower latency, but the float additions run in another order, so the
+        # bits then depend on the batch size; off unless asked for
+        self.ksplit = ksplit
         self.fuse_pyramid_pool = fuse_pyramid_pool
         self.fuse_stem2 = fuse_stem2
         self.fuse_dual = fuse_dual
@@ -1119,14 +1125,28 @@ class CompiledGraph(object):
             if info[6] == self.mfma_edge and not (self.split and (info[4] // (16 * (64 // info[6]))) % 2):
                 candidates.append(cfg)
                 tile_n[cfg] = info[1]
+        # small-tile configurations: the ones a split-K launch is tried with
+        small = []
+        for cfg in candidates:
+            _lib.call('fss_conv_config_info', cfg, info)
+            if info[0] * info[1] <= 128 * 64:
+                small.append(cfg)
         e0 = e1 = None
         ms = ctypes.c_float()
-        for s, fname in zip(self.steps, self.step_fname):
+        tune_ws = None
+        for idx, (s, fname) in enumerate(zip(self.steps, self.step_fname)):
             if s.kind != 'conv':
                 continue
             d = s.keep[0] if isinstance(s.keep, tuple) else s.keep
             key = ','.join(str(getattr(d, f[0])) for f in d._fields_ if f[0] != 'config')
             cands = candidates
+            # split-K candidates: an output too small to fill the chip (at most four 64x64 tiles
+            # per CU) under a long K axis, i.e. the late backbone blocks at one or two frames
+            m_rows = d.n * d.ho * d.wo
+            ksplits = ()
+            if (fname == 'fss_conv2d_nhwc' and self.ksplit and m_rows * d.cout <= 64 * 64 * 256 * 4
+                    and d.kh * d.kw * d.cin >= 1024):
+                ksplits = (2, 4, 8)
             if fname == 'fss_conv2d_dual_nhwc':
                 key += ',%d,%d,dual%d' % (s.args[6] is not None, self.mfma_edge, s.args[3])
             elif fname == 'fss_conv2d_dual_head_nhwc':
@@ -1136,6 +1156,8 @@ class CompiledGraph(object):
                 cands = [c for c in candidates if tile_n[c] >= max(d.cout, 128)]
             else:
                 key += ',%d,%d' % (s.args[4] is not None, self.mfma_edge)
+            if ksplits:
+                key += ',ksplit'           # timed with the split-K candidates as well
             best = cache.get(key)
             if best is None:
                 if e0 is None:
@@ -1143,21 +1165,39 @@ class CompiledGraph(object):
                     _lib.call('fss_event_create', ctypes.byref(e0))
                     _lib.call('fss_event_create', ctypes.byref(e1))
                 best, best_ms = 0, float('inf')
-                for cfg in cands:
+                trials = [(cfg, 1) for cfg in cands] + [(cfg, k) for k in ksplits for cfg in small]
+                if ksplits:
+                    need = max(ksplits) * m_rows * ((d.cout + 3) // 4 * 4) * 4
+                    if tune_ws is None or tune_ws.numel() * 4 < need:
+                        tune_ws = torch.empty(need // 4, dtype=torch.float32, device=self.device)
+                for cfg, k in trials:
                     d.config = cfg
+                    fn, args = s.fn, s.args
+                    if k > 1:
+                        fn = lib.fss_conv2d_splitk_nhwc
+                        args = s.args[:6] + (k, tune_ws.data_ptr(), tune_ws.numel() * 4, s.args[6])
                     for _ in range(warm):
-                        check(s.fn(*s.args), s.name)
+                        check(fn(*args), s.name)
                     _lib.call('fss_event_record', e0, self.sh)
                     for _ in range(reps):
-                        check(s.fn(*s.args), s.name)
+                        check(fn(*args), s.name)
                     _lib.call('fss_event_record', e1, self.sh)
                     _lib.call('fss_event_sync', e1)
                     _lib.call('fss_event_elapsed_ms', e0, e1, ctypes.byref(ms))
                     if ms.value < best_ms:
-                        best, best_ms = cfg, ms.value
+                        best, best_ms = cfg + 1000 * (k if k > 1 else 0), ms.value
                 cache[key] = best
                 self.tuned_now += 1
-            d.config = best
+            d.config = best % 1000
+            if best >= 1000 and fname == 'fss_conv2d_nhwc':
+                # the split-K form of this launch, with a workspace of its own (the slabs are
+                # written and read by this step only)
+                k = best // 1000
+                ws = torch.empty(k * m_rows * ((d.cout + 3) // 4 * 4), dtype=torch.float32, device=self.device)
+                self.workspaces.append(ws)
+                s.fn = lib.fss_conv2d_splitk_nhwc
+                s.args = s.args[:6] + (k, ws.data_ptr(), ws.numel() * 4, s.args[6])
+                self.step_fname[idx] = 'fss_conv2d_splitk_nhwc'
         if e0 is not None:
             _lib.call('fss_event_destroy', e0)
             _lib.call('fss_event_destroy', e1)
@@ -1437,5 +1477,6 @@ class CompiledGraph(object):
             _lib.call('fss_event_destroy', e)
         return [dict(kind=s.kind, name=s.name, ms=best[k], mean_ms=total[k] / repeats, flops=s.flops, graph_flops=s.graph_flops, bytes=s.bytes,
                      config=((s.keep[0] if isinstance(s.keep, tuple) else s.keep).config
+                             + (1000 * s.args[6] if self.step_fname[k] == 'fss_conv2d_splitk_nhwc' else 0)
                              if s.kind == 'conv' else None))
                 for k, s in enumerate(self.steps)]

@@ -124,6 +124,17 @@ int fss_conv_config_info(int config, int info[7]);
 int fss_conv2d_nhwc(const fss_conv_desc* desc, const void* x, const void* w_packed,
                     const float* bias, const void* residual, void* y, void* stream);
 
+/* The same convolution with the K axis split over `splits` (2..16) blocks per output tile, for
+ * layers whose output has too few tiles to fill the chip (a few thousand pixels, K in the
+ * thousands: the backbone's late blocks at one frame per launch).  Two launches: the blocks store
+ * raw float sums of their K share into slab z of `workspace` ([splits][n*ho*wo][round_up(cout, 4)]
+ * floats, workspace_bytes >= that), then one pass adds the slabs in index order and applies bias,
+ * residual and activation.  Same call sites as fss_conv2d_nhwc; the result differs from it only
+ * by the order of the float additions. */
+int fss_conv2d_splitk_nhwc(const fss_conv_desc* desc, const void* x, const void* w_packed,
+                           const float* bias, const void* residual, void* y, int splits,
+                           float* workspace, size_t workspace_bytes, void* stream);
+
 /* Sum of two convolutions in one launch:
  *   y = act(conv(x, W) + conv1x1(x2, W2) + bias [+ residual])
  * x2: [n,ho,wo,cin2] (the output's spatial size, stride 1).  Packed weights: the K axis

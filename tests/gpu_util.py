@@ -51,8 +51,9 @@ def pack_conv_weights(w, dt, cin_phys=None):
 
 
 def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw=None,
-           act=None, dt='f32', out_dt=None, y_ld=None, config=0):
-    """x: [n,h,w,cin] float32 host array; returns float32 host array [n,ho,wo,cout]."""
+           act=None, dt='f32', out_dt=None, y_ld=None, config=0, splits=1):
+    """x: [n,h,w,cin] float32 host array; returns float32 host array [n,ho,wo,cout].
+    splits > 1: through fss_conv2d_splitk_nhwc."""
     out_dt = out_dt or dt
     n, h, wd, cin = x.shape
     kh, kw, _, cout = w.shape
@@ -68,9 +69,18 @@ def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw
                       act=_lib.ACT_CODES[act], in_dtype=conv_in_code(dt), out_dtype=DT[out_dt][0],
                       y_ld=ld, res_ld=cout, k_pad=k_pad, cout_pad=cout_pad, config=config)
     torch.cuda.synchronize()
-    _lib.call('fss_conv2d_nhwc', ctypes.byref(d), xd.data_ptr(), wdev.data_ptr(),
-              bd.data_ptr() if bd is not None else None,
-              rd.data_ptr() if rd is not None else None, y.data_ptr(), None)
+    if splits > 1:
+        ws = torch.full((splits * n * ho * wo * ((cout + 3) // 4 * 4) + 64,), float('nan'), device='cuda')
+        _lib.call('fss_conv2d_splitk_nhwc', ctypes.byref(d), xd.data_ptr(), wdev.data_ptr(),
+                  bd.data_ptr() if bd is not None else None,
+                  rd.data_ptr() if rd is not None else None, y.data_ptr(), splits,
+                  ws.data_ptr(), (ws.numel() - 64) * 4, None)
+        _lib.call('fss_device_sync')
+        assert bool(torch.isnan(ws[-64:]).all()), 'split-K launch wrote past its slabs'
+    else:
+        _lib.call('fss_conv2d_nhwc', ctypes.byref(d), xd.data_ptr(), wdev.data_ptr(),
+                  bd.data_ptr() if bd is not None else None,
+                  rd.data_ptr() if rd is not None else None, y.data_ptr(), None)
     _lib.call('fss_device_sync')
     out = to_host(y)
     if ld != cout:

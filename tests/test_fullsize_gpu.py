@@ -81,8 +81,20 @@ def test_full_size_bf16_properties():
     g1, _, outs1, _ = build(*CASE, (1, 1024, 2048, 3), PAD)
     cg1 = plan.CompiledGraph(g1, outs1, weights, dtype='bfloat16')
     logits1, labels1 = cg1.run(frames[1:2])
+    del cg1
     assert np.array_equal(logits1[0], logits2[1])
     assert np.array_equal(labels1[0], labels2[1])
+    # 5. the low-latency plan (split-K launches in the late backbone blocks: another order of the
+    #    float additions) agrees with it within bf16 rounding steps
+    cgk = plan.CompiledGraph(g1, outs1, weights, dtype='bfloat16', ksplit=True)
+    logitsk, labelsk = cgk.run(frames[1:2])
+    nsplit = sum(f == 'fss_conv2d_splitk_nhwc' for f in cgk.step_fname)
+    scale = float(np.abs(logits1).max())
+    err = float(np.abs(logitsk - logits1).max()) / scale
+    agree = float((labelsk == labels1).mean())
+    print('split-K plan vs plain plan, one bf16 frame: %d split-K launches, logit diff %.3g of scale, '
+          'labels equal %.5f' % (nsplit, err, agree))
+    assert nsplit > 0 and err <= 2e-2 and agree >= 0.99
 
 
 def _scores_of(cg):

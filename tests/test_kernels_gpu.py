@@ -104,6 +104,47 @@ def test_conv2d_epilogue(dt, act):
     _close(got, ref, 2e-4 if dt != 'bf16' else 1.0 / 128, 'conv epilogue %s %s' % (dt, act))
 
 
+SPLITK_CASES = [
+    # n, h, w, cin, cout, k, rate, splits, config
+    (1, 33, 65, 256, 256, 3, 4, 4, 22),     # backbone block at one frame; taps skipped at the border
+    (1, 33, 65, 512, 96, 1, 1, 2, 21),      # 1x1
+    (2, 9, 11, 64, 40, 3, 16, 8, 22),       # most taps read only padding: fewer K tiles than splits
+    (1, 17, 23, 24, 72, 3, 2, 3, 0),        # cin below the K tile (per-lane tap walk), automatic config
+]
+
+
+@pytest.mark.parametrize('case', SPLITK_CASES)
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
+def test_conv2d_splitk_matches_the_plain_launch(case, dt):
+    """fss_conv2d_splitk_nhwc = fss_conv2d_nhwc up to the order of the float additions, with bias,
+    residual, activation and a wider output pixel stride; also against the oracle."""
+    gu = _gu()
+    n, h, wd, cin, cout, k, rate, splits, config = case
+    if dt == 'f32x3' and config == 21:
+        config = 22                          # the split-bf16 mode needs an even number of k steps
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    x = rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32)
+    w = rng.normal(0, 1 / np.sqrt(k * k * cin), (k, k, cin, cout)).astype(np.float32)
+    bias = rng.normal(0, 0.5, cout).astype(np.float32)
+    res = rng.normal(0, 1, (n, h, wd, cout)).astype(np.float32)
+    if dt == 'bf16':
+        x, w, res = gu.bf16_round(x), gu.bf16_round(w), gu.bf16_round(res)
+    pads, out_hw = _conv_pads(h, wd, k, 1, rate, 'SAME')
+    ref = O.relu(_conv_ref(x, w, 1, rate, 'SAME') + bias + res)
+    plain = gu.conv2d(x, w, bias, res, 1, rate, pads, out_hw, 'relu', dt, y_ld=cout + 8, config=config)
+    split = gu.conv2d(x, w, bias, res, 1, rate, pads, out_hw, 'relu', dt, y_ld=cout + 8, config=config,
+                      splits=splits)
+    tol = 1.0 / 128 if dt == 'bf16' else 2e-4
+    _close(split, ref, tol, 'split-K conv %s %s' % (dt, case,))
+    # same products, another summation order: one output rounding step apart at most
+    _close(split, plain, 1.0 / 200 if dt == 'bf16' else 1e-5, 'split-K vs plain %s %s' % (dt, case,))
+    # float output of bf16 inputs (the classifier form of the plain entry point)
+    if dt == 'bf16':
+        s32 = gu.conv2d(x, w, bias, None, 1, rate, pads, out_hw, None, dt, out_dt='f32', config=config,
+                        splits=splits)
+        _close(s32, _conv_ref(x, w, 1, rate, 'SAME') + bias, 2e-4, 'split-K float output %s' % (case,))
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 def test_conv2d_configs_agree_bitwise(dt):
     """Tile configurations with the same MFMA shape accumulate each output over k

@@ -17,7 +17,7 @@ import numpy as np
 
 CASES = {
     # name: (config file, input shape, pad shape, batches)
-    'icnet10': ('single_stage_icnet_1.0_1025_resnet_v1.config', (1024, 2048, 3), (1025, 2049), (1, 16, 32, 64)),
+    'icnet10': ('single_stage_icnet_1.0_1025_resnet_v1.config', (1024, 2048, 3), (1025, 2049), (1, 16, 32, 64, 128)),
     'pspnet713': ('pspnet_1.0_713_resnet_v1.config', (713, 713, 3), (713, 713), (1, 8, 16)),
     'icnet05': ('two_stage_icnet_0.5_1025_resnet_v1_stage_2.config', (1024, 2048, 3), (1025, 2049), (1, 32, 64)),
     'icnet_mnv2': ('single_stage_icnet_1.0_1025_mobilenet_v2.config', (1024, 2048, 3), (1025, 2049), (1, 16, 64)),
@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--dtype', default='bfloat16')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--layers', default=None)
+    ap.add_argument('--ksplit', action='store_true', help='split-K launches where they are faster (small batches)')
     args = ap.parse_args()
     from google.protobuf import text_format
     from protos import pipeline_pb2
@@ -48,7 +49,7 @@ def main():
                                                                pad_shape[1], False, b)
             istd = 0.55 if 'mobilenet' in cfg_file else 70.0
             weights = synth.make_weights(g.variables, input_std=istd)
-            cg = plan.CompiledGraph(g, [preds], weights, dtype=args.dtype)
+            cg = plan.CompiledGraph(g, [preds], weights, dtype=args.dtype, ksplit=args.ksplit)
             cg.set_input(np.random.default_rng(0).integers(0, 256, (b,) + in_shape).astype(np.uint8))
             for _ in range(3):
                 cg.launch()

@@ -18,7 +18,7 @@ SHAPES = {  # name: (h, w, cin, cout, k, stride, rate, residual)
     'cff1_dil': (129, 257, 256, 256, 3, 1, 2, False),
     'cff0_dil': (65, 129, 512, 256, 3, 1, 2, False),
     'conv_3': (129, 257, 128, 256, 3, 1, 1, False),
-    'b4_conv2': (33, 65, 512, 512, 3, 1, 16, False),
+    'b4_conv2': (33, 65, 512, 512, 3, 1, 4, False),
     'b4_conv3': (33, 65, 512, 2048, 1, 1, 1, True),
     'b4_conv1': (33, 65, 2048, 512, 1, 1, 1, False),
     'b3_conv2': (33, 65, 256, 256, 3, 1, 4, False),
@@ -35,6 +35,7 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--cfg', type=int, default=0)
+    ap.add_argument('--cfgs', default='', help='comma-separated configurations to sweep (overrides --cfg)')
     ap.add_argument('--nores', action='store_true', help='drop the residual input')
     args = ap.parse_args()
     from fss import _lib
@@ -63,20 +64,22 @@ def main():
         def run():
             _lib.call('fss_conv2d_nhwc', ctypes.byref(d), x.data_ptr(), wdev.data_ptr(), bias.data_ptr(),
                       res.data_ptr() if res is not None else None, y.data_ptr(), None)
-        for _ in range(3):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / args.iters
-        flops = 2.0 * n * ho * wo * cout * k * k * cin
-        nbytes = (x.numel() + y.numel() * (2 if has_res else 1)) * x.element_size()
-        print('%-10s M=%7d N=%4d K=%5d  %8.4f ms  %7.1f TFLOP/s  %7.1f GB/s' %
-              (name, n * ho * wo, cout, k * k * cin, ms, flops / ms / 1e9, nbytes / ms / 1e6), flush=True)
+        for cfg in ([int(c) for c in args.cfgs.split(',')] if args.cfgs else [args.cfg]):
+            d.config = cfg
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            flops = 2.0 * n * ho * wo * cout * k * k * cin
+            nbytes = (x.numel() + y.numel() * (2 if has_res else 1)) * x.element_size()
+            print('%-10s cfg %2d M=%7d N=%4d K=%5d  %8.4f ms  %7.1f TFLOP/s  %7.1f GB/s' %
+                  (name, cfg, n * ho * wo, cout, k * k * cin, ms, flops / ms / 1e9, nbytes / ms / 1e6), flush=True)
 
 
 if __name__ == '__main__':

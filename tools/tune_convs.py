@@ -44,9 +44,12 @@ def main():
         preds, _ = evaluator.create_predictions_and_labels(model, in_shape, pad_shape[0], pad_shape[1],
                                                            False, b)
         weights = synth.make_weights(g.variables, input_std=0.55 if 'mobilenet' in cfg_file else 70.0)
-        cg = plan.CompiledGraph(g, [preds], weights, dtype=dtype, mfma_edge=e, use_hip_graph=False)
-        print('%s %s b%d edge %d: %d shapes timed' % (name, dtype, b, e, cg.tuned_now), flush=True)
-        del cg
+        for ksplit in ((False, True) if b == 1 else (False,)):       # one frame: the low-latency plan too
+            cg = plan.CompiledGraph(g, [preds], weights, dtype=dtype, mfma_edge=e, use_hip_graph=False,
+                                    ksplit=ksplit)
+            print('%s %s b%d edge %d%s: %d shapes timed' % (name, dtype, b, e, ' split-K' if ksplit else '',
+                                                            cg.tuned_now), flush=True)
+            del cg
         plan.CompiledGraph.save_tuning(args.out)
     print('wrote', args.out, len(plan.CompiledGraph._TUNE_CACHE), 'entries')
 
