@@ -315,9 +315,18 @@ conv_igemm_kernel(const ConvArgs a) {
   const unsigned r2step = (unsigned)(RSTEP * a.Cin2 * (int)sizeof(T));
   const char* wptr[B_IT];
 #pragma unroll
-  for (int i = 0; i < B_IT; ++i)
-    wptr[i] = reinterpret_cast<const char*>(wgt + (size_t)(tile_n * BN + row0 + i * RSTEP) * a.Kpad +
-                                            chunk * EPC);
+  for (int i = 0; i < B_IT; ++i) {
+    int wrow = row0 + i * RSTEP;             // row of the B tile = output channel of the N tile
+    if constexpr (HEAD) {
+      // classifier-head form: tile row 16 j + 4 g + q of a wave's slice holds channel
+      // 32 (j >> 1) + 8 g + 4 (j & 1) + q, so that the 8 accumulator values a lane owns in the
+      // tile pair (2 s, 2 s + 1) are 8 CONSECUTIVE channels: its residual and classifier
+      // operands are then single 16-byte loads
+      const int l = wrow % (BN / WAVES_N);
+      wrow += (((l >> 5) << 5) + (((l >> 2) & 3) << 3) + (((l >> 4) & 1) << 2) + (l & 3)) - l;
+    }
+    wptr[i] = reinterpret_cast<const char*>(wgt + (size_t)(tile_n * BN + wrow) * a.Kpad + chunk * EPC);
+  }
 
   // tap walk.  ALIGNED: (kc, tap = kr*KW + ks) = channel base / tap of the whole tile
   // (uniform); taps that read padding for EVERY row of this block are skipped, and so
@@ -513,9 +522,10 @@ conv_igemm_kernel(const ConvArgs a) {
     fill = fill + 1 == NSTAGE ? 0 : fill + 1;
   }
   if constexpr (HEAD) {
-    // acc[i][j] is D[channel][pixel]: lane (lrow, lg) holds channels 16 j + 4 lg + q of pixel
-    // 16 i + lrow of this wave's tile.  Second product, per 32 channels (two D tiles): k
-    // index 8 lg + e of both operands = channel 32 s + 4 lg + (e & 3) + 16 (e >> 2).
+    // acc[i][j] is D[channel][pixel]: lane (lrow, lg) holds, for pixel 16 i + lrow of this wave's
+    // tile, tile rows 16 j + 4 lg + q = channels 32 (j >> 1) + 8 lg + 4 (j & 1) + q (the weight
+    // rows were fetched in that order).  Second product, per 32 channels (two D tiles): k index
+    // 8 lg + e of both operands = channel 32 s + 8 lg + e.
     static_assert(FM == 16 && sizeof(T) == 2 && NI % 2 == 0, "head epilogue: 16x16x32 bf16 tiles");
     static_assert(WAVES_N * BM * kHeadMax * 4 <= NSTAGE * STAGE_BYTES, "head staging does not fit");
     wait_vmcnt<0>();
@@ -536,14 +546,12 @@ conv_igemm_kernel(const ConvArgs a) {
       uint4 wa[2];
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
-        const T* p = wh + (size_t)(ct * 16 + lrow) * a.Cout + c0 + 4 * lg;
-        const uint2 lo = *reinterpret_cast<const uint2*>(p), hi = *reinterpret_cast<const uint2*>(p + 16);
-        wa[ct] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        wa[ct] = *reinterpret_cast<const uint4*>(wh + (size_t)(ct * 16 + lrow) * a.Cout + c0 + 8 * lg);
       }
       float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
       if (a.bias != nullptr) {
-        b0 = *reinterpret_cast<const float4*>(a.bias + c0 + 4 * lg);
-        b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 16 + 4 * lg);
+        b0 = *reinterpret_cast<const float4*>(a.bias + c0 + 8 * lg);
+        b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 8 * lg + 4);
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
@@ -551,12 +559,12 @@ conv_igemm_kernel(const ConvArgs a) {
         if (a.zy != nullptr) {
           // residual = corrected x2 zoom of zy at this lane's pixel: the mean of 1, 2 or 4
           // sources, formed branch-free as a quarter of the sum over the 2 x 2 neighbourhood
-          // with the indices clamped (a source counted twice or four times), so that the 8
+          // with the indices clamped (a source counted twice or four times), so that the 4
           // loads are independent and in flight together
           const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
           const int f = m / HoWo, rem = m - f * HoWo;
           const int p = rem / a.Wo, q = rem - p * a.Wo;
-          uint2 u0[4], u1[4];
+          uint4 u[4];
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb) {
             const int zi = (p >> 1) + ((nb >> 1) & p), zj = (q >> 1) + (nb & q & 1);
@@ -569,29 +577,27 @@ conv_igemm_kernel(const ConvArgs a) {
               src = reinterpret_cast<const T*>(a.zylr) + (((size_t)(cf - 1) * a.N + f) * a.zH + zi) * a.Cout;
             if (rf != 0 && cf != 0)
               src = reinterpret_cast<const T*>(a.zycn) + ((size_t)((rf - 1) * 2 + (cf - 1)) * a.N + f) * a.Cout;
-            src += c0 + 4 * lg;
-            u0[nb] = *reinterpret_cast<const uint2*>(src);
-            u1[nb] = *reinterpret_cast<const uint2*>(src + 16);
+            u[nb] = *reinterpret_cast<const uint4*>(src + c0 + 8 * lg);
           }
           float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int nb = 0; nb < 4; ++nb) {
-            r0[0] += __uint_as_float(u0[nb].x << 16); r0[1] += __uint_as_float(u0[nb].x & 0xffff0000u);
-            r0[2] += __uint_as_float(u0[nb].y << 16); r0[3] += __uint_as_float(u0[nb].y & 0xffff0000u);
-            r1[0] += __uint_as_float(u1[nb].x << 16); r1[1] += __uint_as_float(u1[nb].x & 0xffff0000u);
-            r1[2] += __uint_as_float(u1[nb].y << 16); r1[3] += __uint_as_float(u1[nb].y & 0xffff0000u);
+            r0[0] += __uint_as_float(u[nb].x << 16); r0[1] += __uint_as_float(u[nb].x & 0xffff0000u);
+            r0[2] += __uint_as_float(u[nb].y << 16); r0[3] += __uint_as_float(u[nb].y & 0xffff0000u);
+            r1[0] += __uint_as_float(u[nb].z << 16); r1[1] += __uint_as_float(u[nb].z & 0xffff0000u);
+            r1[2] += __uint_as_float(u[nb].w << 16); r1[3] += __uint_as_float(u[nb].w & 0xffff0000u);
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.25f; d1[e] += r1[e] * 0.25f; }
         } else if (a.res != nullptr) {
           const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
           if (m < a.M) {
-            const T* rp = reinterpret_cast<const T*>(a.res) + (size_t)m * a.res_ld + c0 + 4 * lg;
-            const uint2 r0 = *reinterpret_cast<const uint2*>(rp), r1 = *reinterpret_cast<const uint2*>(rp + 16);
-            d0[0] += __uint_as_float(r0.x << 16); d0[1] += __uint_as_float(r0.x & 0xffff0000u);
-            d0[2] += __uint_as_float(r0.y << 16); d0[3] += __uint_as_float(r0.y & 0xffff0000u);
-            d1[0] += __uint_as_float(r1.x << 16); d1[1] += __uint_as_float(r1.x & 0xffff0000u);
-            d1[2] += __uint_as_float(r1.y << 16); d1[3] += __uint_as_float(r1.y & 0xffff0000u);
+            const uint4 rv = *reinterpret_cast<const uint4*>(
+                reinterpret_cast<const T*>(a.res) + (size_t)m * a.res_ld + c0 + 8 * lg);
+            d0[0] += __uint_as_float(rv.x << 16); d0[1] += __uint_as_float(rv.x & 0xffff0000u);
+            d0[2] += __uint_as_float(rv.y << 16); d0[3] += __uint_as_float(rv.y & 0xffff0000u);
+            d1[0] += __uint_as_float(rv.z << 16); d1[1] += __uint_as_float(rv.z & 0xffff0000u);
+            d1[2] += __uint_as_float(rv.w << 16); d1[3] += __uint_as_float(rv.w & 0xffff0000u);
           }
         }
         auto cl = [&](float v) { return fminf(fmaxf(v, act_lo), act_hi); };
@@ -996,12 +1002,12 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
   FSS_REQUIRE(cout_head > 0 && cout_head <= kHeadMax, "cout_head out of range");
   FSS_REQUIRE(y_head_ld >= cout_head, "y_head_ld < cout_head");
   FSS_REQUIRE(d->cout % 32 == 0 && d->cout <= 256, "cout must be a multiple of 32, at most 256");
-  FSS_REQUIRE(((uintptr_t)w_head & 7) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0),
+  FSS_REQUIRE(((uintptr_t)w_head & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0),
               "unaligned pointer");
   ConvArgs a;
   fss_conv_desc dd = *d;
   dd.y_ld = d->cout;        // no activation tensor is written; keep the shared checks satisfied
-  FSS_REQUIRE(residual == nullptr || (((uintptr_t)residual & 7) == 0 && d->res_ld % 4 == 0),
+  FSS_REQUIRE(residual == nullptr || (((uintptr_t)residual & 15) == 0 && d->res_ld % 8 == 0),
               "unaligned residual");
   if (int rc = conv_setup(&dd, x, x2, cin2, w_packed, bias, residual, y_head, a)) return rc;
   const int bk = 64;        // widest K tile in elements (128-byte tile rows of bf16)
@@ -1012,7 +1018,7 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
     FSS_REQUIRE(zh >= 4 && zw >= 4 && d->ho == 2 * zh - 1 && d->wo == 2 * zw - 1,
                 "zoom_residual: the output must be (2 zh - 1) x (2 zw - 1), zh, zw >= 4");
     for (int i = 0; i < 4; ++i)
-      FSS_REQUIRE(zoom_residual[i] != nullptr && ((uintptr_t)zoom_residual[i] & 7) == 0,
+      FSS_REQUIRE(zoom_residual[i] != nullptr && ((uintptr_t)zoom_residual[i] & 15) == 0,
                   "zoom_residual: null or unaligned tensor");
     a.zy = zoom_residual[0]; a.zytb = zoom_residual[1]; a.zylr = zoom_residual[2]; a.zycn = zoom_residual[3];
     a.zH = zh; a.zW = zw;
