@@ -43,7 +43,9 @@ def main(argv=None):
     ap.add_argument('--image_summaries', action='store_true')
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--limit_gpu_mem', action='store_true')
-    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32', 'float32x3'])
+    ap.add_argument('--dtype', default='float32x3', choices=['bfloat16', 'float32', 'float32x3'],
+                    help='float32x3 (default): float32 tensors, products as three bf16 MFMAs - the results of a '
+                         'float32 framework; bfloat16: 3x the throughput, labels differ on 0.1 - 2 %% of the pixels')
     ap.add_argument('--batch_size', type=int, default=1)
     flags = ap.parse_args(argv)
 

@@ -155,7 +155,8 @@ class CompiledGraph(object):
         self.graph_exec = None
         self.param_bytes = 0
         # MFMA shape class of the conv kernel: 16 (v_mfma_*_16x16*) or 32 (v_mfma_*_32x32*)
-        self.mfma_edge = int(mfma_edge or os.environ.get('FSS_MFMA_EDGE', 16 if self.dt == 'bf16' else 32))
+        self.mfma_edge = int(mfma_edge or os.environ.get('FSS_MFMA_EDGE',
+                                                         16 if (self.dt == 'bf16' or self.split) else 32))
         if self.mfma_edge not in (16, 32):
             raise ValueError('mfma_edge must be 16 or 32')
         self.fuse_stem = fuse_stem

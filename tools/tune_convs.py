@@ -28,7 +28,7 @@ def main():
         plan.CompiledGraph._TUNE_CACHE = {}
     jobs = []
     for name, (cfg_file, in_shape, pad_shape, batches) in CASES.items():
-        for dtype, edges in (('bfloat16', (16, 32)), ('float32', (32, 16)), ('float32x3', (32,))):
+        for dtype, edges in (('bfloat16', (16, 32)), ('float32', (32, 16)), ('float32x3', (16, 32))):
             for b in batches:
                 if dtype == 'float32' and name not in ('icnet10',):      # float32x3: every model
                     continue
