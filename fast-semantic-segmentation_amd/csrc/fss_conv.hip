@@ -42,7 +42,7 @@
 // buffer.
 #include <type_traits>
 
-#include "fss_common.h"
+#include "fss_conv_args.h"
 
 namespace fss {
 
@@ -51,32 +51,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 // 16 zero bytes every padding tap is fetched from.
 __device__ __attribute__((aligned(16))) unsigned int g_zero_chunk[4] = {0u, 0u, 0u, 0u};
-
-struct ConvArgs {
-  const void* x;
-  const void* x2;   // second input (1x1, stride 1, the output's spatial size), or null
-  const void* w;
-  const float* bias;
-  const void* res;
-  void* y;
-  int N, H, W, Cin, Cout, KH, KW, stride, dil, pad_t, pad_l, Ho, Wo, act;
-  int Cin2;         // channels of x2: its K segment follows the filter taps in the packed weights
-  int M, K, Kpad, y_ld, res_ld, tiles_m, tiles_n;
-  // split-K launches: the grid holds `splits` blocks per output tile, block z of a tile walks
-  // its share of the tile's K tiles and stores raw sums into slab z of y ([splits][M][y_ld])
-  int splits;
-  // classifier head (HEAD kernels only): logits = act(conv) * w_head^T + bias_head
-  const void* w_head;       // bf16 [32][Cout], rows >= cout_head zero
-  const float* bias_head;   // [cout_head]
-  int cout_head;
-  // residual of the HEAD kernels given as the x2 zoom of a half-resolution tensor zy[N][zH][zW][Cout]
-  // (+ the border substitutes of fss_zoom2_conv_commute), interpolated in the epilogue
-  const void* zy;
-  const void* zytb;
-  const void* zylr;
-  const void* zycn;
-  int zH, zW;
-};
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -183,26 +157,6 @@ template <> struct Mma<f32s_t, 16> : Mma<bf16_t, 16> {
     Mma<bf16_t, 16>::run(acc, ahi, bhi);
   }
 };
-
-// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to the
-// 1 KiB of LDS starting at the wave-uniform byte address `lds_dst`.  M0 (the DMA's
-// LDS base) is written and consumed inside the one statement and declared clobbered,
-// so the compiler never keeps a value of its own (s_movrel / gpr-index setup) in it
-// across the statement.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  asm volatile(
-      "s_mov_b32 m0, %1\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %0, off"
-      :
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory", "m0");
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 63, "vmcnt out of range");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // ALIGNED: cin is a multiple of the K tile, so a tile never straddles two filter
 // taps and the tap walk is wave-uniform (scalar) instead of per lane.
@@ -836,7 +790,10 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   X(32, 128, 64, 4, 2, 128, 2, 16)  \
   X(33, 128, 256, 2, 4, 64, 2, 16)  \
   X(34, 128, 256, 2, 4, 64, 3, 16)
-static constexpr int kNumConvConfigs = 34;
+// configuration 35: the 8-wave, 8-phase 256x256 kernel of fss_conv8.hip (bf16 in and out, cin in
+// whole K tiles); for every other layer it stands for configuration 28, whose results are the same
+static constexpr int kConv8Config = 35;
+static constexpr int kNumConvConfigs = 35;
 
 // automatic choice when the caller does not name a configuration
 static int default_config(const ConvArgs& a) {
@@ -852,6 +809,13 @@ static int default_config(const ConvArgs& a) {
 template <typename T, typename TO>
 static int dispatch_conv(ConvArgs& a, int config, hipStream_t stream) {
   if (config == 0) config = default_config(a);
+  if (config == kConv8Config) {
+    if constexpr (std::is_same<T, bf16_t>::value && std::is_same<TO, bf16_t>::value) {
+      const int rc = launch_conv8_bf16(a, stream);
+      if (rc >= 0) return rc;
+    }
+    config = 28;
+  }
   switch (config) {
 #define FSS_CASE(ID, BM, BN, WM, WN, BKB, NS, FM) \
   case ID: return launch_conv<T, TO, BM, BN, WM, WN, BKB, NS, FM>(a, stream);
@@ -877,6 +841,7 @@ static int launch_conv_head(ConvArgs& a, hipStream_t stream) {
 
 static int dispatch_conv_head(ConvArgs& a, int config, hipStream_t stream) {
   if (config == 0) config = a.Cout > 128 ? 28 : 29;
+  if (config == kConv8Config) config = 28;
   int rc = -1;
   switch (config) {
 #define FSS_CASE(ID, BM, BN, WM, WN, BKB, NS, FM) \
@@ -920,6 +885,11 @@ extern "C" int fss_conv_config_info(int config, int info[7]) {
   }
     FSS_CONV_CONFIGS(FSS_INFO)
 #undef FSS_INFO
+    case kConv8Config: {
+      const int v[7] = {256, 256, 2, 4, 128, 2, 16};
+      for (int i = 0; i < 7; ++i) info[i] = v[i];
+      return 0;
+    }
     default: break;
   }
   set_error("fss_conv_config_info: config out of range");

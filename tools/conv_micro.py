@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--cfg', type=int, default=0)
     ap.add_argument('--cfgs', default='', help='comma-separated configurations to sweep (overrides --cfg)')
     ap.add_argument('--nores', action='store_true', help='drop the residual input')
+    ap.add_argument('--zeros', action='store_true', help='zero-filled operands (no data toggling: the clock-limited ceiling)')
     args = ap.parse_args()
     from fss import _lib
     import gpu_util as gu
@@ -54,6 +55,9 @@ def main():
         wt = np.random.default_rng(0).normal(0, 1 / np.sqrt(k * k * cin), (k, k, cin, cout)).astype(np.float32)
         wdev, k_pad, cout_pad = gu.pack_conv_weights(wt, args.dtype)
         bias = torch.randn(cout, device='cuda')
+        if args.zeros:
+            x.zero_()
+            wdev.zero_()
         res = torch.randn((n, ho, wo, cout), device='cuda', generator=g).to(tdt) if has_res else None
         y = torch.empty((n, ho, wo, cout), device='cuda', dtype=tdt)
         d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=k, kw=k, stride=stride, dilation=rate,

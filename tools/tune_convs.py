@@ -5,6 +5,7 @@ configurations and writes the winners to a table the plan compiler loads at impo
 usage (on a GPU box): python tools/tune_convs.py [--out gpurun_out/conv_tuned.json]
 """
 import argparse
+import gc
 import os
 import sys
 
@@ -24,6 +25,7 @@ def main():
     from fss import graph as G, synth, plan
     from libs import evaluator
     from bench_configs import CASES
+    import torch
     if args.fresh:
         plan.CompiledGraph._TUNE_CACHE = {}
     jobs = []
@@ -50,6 +52,8 @@ def main():
             print('%s %s b%d edge %d%s: %d shapes timed' % (name, dtype, b, e, ' split-K' if ksplit else '',
                                                             cg.tuned_now), flush=True)
             del cg
+            gc.collect()
+            torch.cuda.empty_cache()
         plan.CompiledGraph.save_tuning(args.out)
     print('wrote', args.out, len(plan.CompiledGraph._TUNE_CACHE), 'entries')
 
