@@ -212,19 +212,30 @@ conv_igemm_kernel(const ConvArgs a) {
   // this lane fills physical chunk (tid % CPR) of its rows with logical chunk `chunk`
   const int chunk = (tid % CPR) ^ swizzle_of(row0);
 
-  const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ wgt = reinterpret_cast<const T*>(a.w);
-  const void* zero_src = reinterpret_cast<const void*>(g_zero_chunk);
-
   const int HoWo = a.Ho * a.Wo;
 
   // 1x1, stride 1, unpadded: the A matrix is the input tensor itself
   const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 &&
                          a.Ho == a.H && a.Wo == a.W;
+  // ---- DMA windows of this block (buffer resources; offsets below are relative to them):
+  // the input from the first image (pointwise: the first pixel) its rows touch, the second
+  // input from its first row, the weights from the first row of its N tile
+  const int m_first = tile_m * BM;
+  const long long pix_first = pointwise ? (long long)m_first : (long long)(m_first / HoWo) * a.H * a.W;
+  const unsigned long long x_bytes = (unsigned long long)a.N * a.H * a.W * a.Cin * sizeof(T);
+  const unsigned long long x_first = (unsigned long long)pix_first * a.Cin * sizeof(T);
+  const fss_i32x4 rs_x = dma_resource(reinterpret_cast<const char*>(a.x) + x_first, x_bytes - x_first);
+  const unsigned long long x2_first = (unsigned long long)m_first * a.Cin2 * sizeof(T);
+  const fss_i32x4 rs_x2 = dma_resource(
+      reinterpret_cast<const char*>(a.x2 != nullptr ? a.x2 : a.x) + x2_first,
+      (unsigned long long)a.M * a.Cin2 * sizeof(T) - x2_first);
+  const fss_i32x4 rs_w = dma_resource(
+      reinterpret_cast<const char*>(a.w) + (size_t)tile_n * BN * a.Kpad * sizeof(T), (size_t)BN * a.Kpad * sizeof(T));
   // ---- per-row gather state
-  // ALIGNED: rptr = address of this lane's chunk at tap (0,0), tapmask bit t = tap t
-  //          of this row reads a real pixel.  Otherwise: explicit coordinates.
-  const char* rptr[A_IT];
+  // ALIGNED: roff = byte offset of this lane's chunk at tap (0,0) in the input window (modulo
+  //          2^32: exact once a real tap's offset is added), tapmask bit t = tap t of this row
+  //          reads a real pixel.  Otherwise: explicit coordinates.
+  unsigned roff[A_IT];
   unsigned long long tapmask[A_IT];
   int ih0[A_IT], iw0[A_IT];
 #pragma unroll
@@ -249,7 +260,7 @@ conv_igemm_kernel(const ConvArgs a) {
       iw0[i] = row_ok ? ow * a.stride - a.pad_l : -(1 << 28);
       pix = ((long long)n * a.H + (row_ok ? ih0[i] : 0)) * a.W + (row_ok ? iw0[i] : 0);
     }
-    rptr[i] = reinterpret_cast<const char*>(xg) + (pix * a.Cin + chunk * EPC) * (long long)sizeof(T);
+    roff[i] = (unsigned)(((pix - pix_first) * a.Cin + chunk * EPC) * (long long)sizeof(T));
     tapmask[i] = 0;
     if constexpr (ALIGNED) {
       for (int r = 0, t = 0; r < a.KH; ++r)
@@ -262,12 +273,11 @@ conv_igemm_kernel(const ConvArgs a) {
       if (a.Cin2 > 0) tapmask[i] |= (unsigned long long)row_ok << (a.KH * a.KW);
     }
   }
-  // second input: byte offset of this lane's chunk in row (tile_m*BM + row0) of x2; the rows
-  // of one lane are RSTEP pixels apart (fits 32 bits: checked by the host)
-  const char* x2c = reinterpret_cast<const char*>(a.x2);
-  const unsigned r2off0 = (unsigned)(((long long)(tile_m * BM + row0) * a.Cin2 + chunk * EPC) * (long long)sizeof(T));
+  // second input: byte offset of this lane's chunk in row row0 of the block's window of x2; the
+  // rows of one lane are RSTEP pixels apart
+  const unsigned r2off0 = (unsigned)((row0 * a.Cin2 + chunk * EPC) * (int)sizeof(T));
   const unsigned r2step = (unsigned)(RSTEP * a.Cin2 * (int)sizeof(T));
-  const char* wptr[B_IT];
+  unsigned woff[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
     int wrow = row0 + i * RSTEP;             // row of the B tile = output channel of the N tile
@@ -279,7 +289,7 @@ conv_igemm_kernel(const ConvArgs a) {
       const int l = wrow % (BN / WAVES_N);
       wrow += (((l >> 5) << 5) + (((l >> 2) & 3) << 3) + (((l >> 4) & 1) << 2) + (l & 3)) - l;
     }
-    wptr[i] = reinterpret_cast<const char*>(wgt + (size_t)(tile_n * BN + wrow) * a.Kpad + chunk * EPC);
+    woff[i] = (unsigned)(((size_t)wrow * a.Kpad + chunk * EPC) * sizeof(T));
   }
 
   // tap walk.  ALIGNED: (kc, tap = kr*KW + ks) = channel base / tap of the whole tile
@@ -354,12 +364,12 @@ conv_igemm_kernel(const ConvArgs a) {
       const int tap_off = ((kr * a.dil * a.W + ks * a.dil) * a.Cin + kc) * (int)sizeof(T);
       const bool second = a.Cin2 > 0 && tap == a.KH * a.KW;          // uniform
       const unsigned off2 = r2off0 + (unsigned)(kc * (int)sizeof(T));
+      const fss_i32x4 rs = second ? rs_x2 : rs_x;                       // uniform
 #pragma unroll
       for (int i = 0; i < A_IT; ++i) {
         const bool ok = in_range && ((tapmask[i] >> tbit) & 1ull);
-        const char* real = second ? x2c + (off2 + i * r2step) : rptr[i] + tap_off;
-        const void* src = ok ? (const void*)real : zero_src;
-        glds16(src, dstA + i * (NT * 16));
+        const unsigned real = second ? off2 + i * r2step : roff[i] + (unsigned)tap_off;
+        blds16(ok ? real : kDmaOutOfRange, rs, dstA + i * (NT * 16));
       }
     } else {
       const int dr = kr * a.dil, ds = ks * a.dil;
@@ -369,18 +379,15 @@ conv_igemm_kernel(const ConvArgs a) {
         const int ih = ih0[i] + dr, iw = iw0[i] + ds;
         const bool ok = k_ok && ((unsigned)ih < (unsigned)a.H) && ((unsigned)iw < (unsigned)a.W);
         const int off = ((dr * a.W + ds) * a.Cin + (kc - chunk * EPC)) * (int)sizeof(T);
-        const void* src = ok ? (const void*)(rptr[i] + off) : zero_src;
-        glds16(src, dstA + i * (NT * 16));
+        blds16(ok ? roff[i] + (unsigned)off : kDmaOutOfRange, rs_x, dstA + i * (NT * 16));
       }
     }
     const bool w_ok = in_range;
     // k index of the tile in the packed weights
     const size_t wk = ALIGNED ? (size_t)(tap * a.Cin + kc) * sizeof(T) : (size_t)kt * BKB;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      const void* src = w_ok ? (const void*)(wptr[i] + wk) : zero_src;
-      glds16(src, dstB + i * (NT * 16));
-    }
+    for (int i = 0; i < B_IT; ++i)
+      blds16(w_ok ? woff[i] + (unsigned)wk : kDmaOutOfRange, rs_w, dstB + i * (NT * 16));
     advance();
   };
 
@@ -930,7 +937,7 @@ static int conv_setup(const fss_conv_desc* d, const void* x, const void* x2, int
   FSS_REQUIRE(d->y_ld >= d->cout, "y_ld < cout");
   FSS_REQUIRE(residual == nullptr || d->res_ld >= d->cout, "res_ld < cout");
   FSS_REQUIRE((long long)d->n * d->ho * d->wo < 0x7fffffffLL, "too many output pixels");
-  FSS_REQUIRE((long long)d->h * d->w * d->cin * esz < 0x7fffffffLL,
+  FSS_REQUIRE((long long)d->h * d->w * d->cin * esz < 0x7fffff00LL,
               "one input image must be smaller than 2 GiB");
   FSS_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0, "unaligned pointer");
 

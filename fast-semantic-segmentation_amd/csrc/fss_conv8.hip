@@ -68,24 +68,35 @@ conv8_kernel(const ConvArgs a) {
   const int prow = tid >> 3;                            // image row of this lane's first piece
   const int chunk = (tid & 7) ^ ((prow >> 1) & 7);      // logical chunk it fetches (rows +64: same)
 
-  const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ wgt = reinterpret_cast<const T*>(a.w);
-  const void* zero_src = reinterpret_cast<const void*>(g_zero_chunk8);
   const int HoWo = a.Ho * a.Wo;
   const int ntap = a.KH * a.KW;
 
   const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad_t == 0 && a.pad_l == 0 &&
                          a.Ho == a.H && a.Wo == a.W;
+  // ---- DMA windows of this block (buffer resources; the offsets below are relative to them)
+  const int m_first = tile_m * kBM;
+  const long long pix_first = pointwise ? (long long)m_first : (long long)(m_first / HoWo) * a.H * a.W;
+  const unsigned long long x_bytes = (unsigned long long)a.N * a.H * a.W * a.Cin * 2;
+  const unsigned long long x_first = (unsigned long long)pix_first * a.Cin * 2;
+  const fss_i32x4 rs_x = dma_resource(reinterpret_cast<const char*>(a.x) + x_first, x_bytes - x_first);
+  const unsigned long long x2_first = (unsigned long long)m_first * a.Cin2 * 2;
+  const fss_i32x4 rs_x2 = dma_resource(
+      reinterpret_cast<const char*>(a.x2 != nullptr ? a.x2 : a.x) + x2_first,
+      (unsigned long long)a.M * a.Cin2 * 2 - x2_first);
+  const fss_i32x4 rs_w = dma_resource(
+      reinterpret_cast<const char*>(a.w) + (size_t)tile_n * kBN * a.Kpad * 2, (size_t)kBN * a.Kpad * 2);
   // ---- gather state of this lane's four pixel rows: image row prow + 64 i of half-tile qm is
-  // tile row 128 i + 64 qm + prow (i = the wave row that reads it)
-  const char* rptr[2][2];
+  // tile row 128 i + 64 qm + prow (i = the wave row that reads it); roff = byte offset of the
+  // lane's chunk at tap (0, 0) in the input window, modulo 2^32
+  unsigned roff[2][2];
   unsigned tapmask[2][2];
   unsigned r2off[2][2];
 #pragma unroll
   for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int m = tile_m * kBM + i * 128 + qm * 64 + prow;
+      const int trow = i * 128 + qm * 64 + prow;
+      const int m = m_first + trow;
       const bool row_ok = m < a.M;
       int n = 0, oh = 0, ow = 0, ih0, iw0;
       long long pix;
@@ -103,7 +114,7 @@ conv8_kernel(const ConvArgs a) {
         iw0 = row_ok ? ow * a.stride - a.pad_l : -(1 << 28);
         pix = ((long long)n * a.H + (row_ok ? ih0 : 0)) * a.W + (row_ok ? iw0 : 0);
       }
-      rptr[qm][i] = reinterpret_cast<const char*>(xg) + (pix * a.Cin + chunk * 8) * 2;
+      roff[qm][i] = (unsigned)(((pix - pix_first) * a.Cin + chunk * 8) * 2);
       unsigned mask = 0;
       for (int r = 0, t = 0; r < a.KH; ++r)
         for (int sx = 0; sx < a.KW; ++sx, ++t) {
@@ -113,18 +124,17 @@ conv8_kernel(const ConvArgs a) {
         }
       if (a.Cin2 > 0) mask |= (unsigned)row_ok << ntap;   // the second input: "one more tap"
       tapmask[qm][i] = mask;
-      r2off[qm][i] = (unsigned)(((long long)(row_ok ? m : 0) * a.Cin2 + chunk * 8) * 2);
+      r2off[qm][i] = (unsigned)((trow * a.Cin2 + chunk * 8) * 2);
     }
-  const char* x2c = reinterpret_cast<const char*>(a.x2);
   // weight rows: image row prow + 64 i of half-tile qn is channel 64 wcol + 32 qn + (prow & 31)
   // of the N tile, wcol = (prow >> 5) + 2 i the wave column that reads it
-  const char* wptr[2][2];
+  unsigned woff[2][2];
 #pragma unroll
   for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int nrow = tile_n * kBN + ((prow >> 5) + 2 * i) * 64 + qn * 32 + (prow & 31);
-      wptr[qn][i] = reinterpret_cast<const char*>(wgt + (size_t)nrow * a.Kpad + chunk * 8);
+      const int nrow = ((prow >> 5) + 2 * i) * 64 + qn * 32 + (prow & 31);
+      woff[qn][i] = (unsigned)(((size_t)nrow * a.Kpad + chunk * 8) * 2);
     }
 
   // ---- taps some row of the block reads for real; the others are skipped
@@ -161,8 +171,8 @@ conv8_kernel(const ConvArgs a) {
     ++skt;
   };
   // issues the two DMA pieces of half-tile J of the K tile being staged into the buffers at
-  // byte offset dofs; K tiles past the last one fetch zeros (every wave keeps the same number
-  // of pieces in flight)
+  // byte offset dofs; K tiles past the last one, padding taps and rows past M deposit zeros
+  // (out-of-range offsets), so every wave keeps the same number of pieces in flight
   auto stage = [&](auto jtag, unsigned dofs) {
     constexpr int J = decltype(jtag)::value;
     const unsigned dst = smem_base + dofs + J * kHalf + wave * 1024;
@@ -172,18 +182,19 @@ conv8_kernel(const ConvArgs a) {
       const int tbit = min(tap, 31);
       const int tap_off = ((kr * a.dil * a.W + ks * a.dil) * a.Cin + kc) * 2;
       const bool second = a.Cin2 > 0 && tap == ntap;
+      const fss_i32x4 rs = second ? rs_x2 : rs_x;                // uniform
+      const unsigned add = second ? (unsigned)(kc * 2) : (unsigned)tap_off;
+      const unsigned bit = in_range && tap < 31 ? 1u << tbit : 0u;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const bool ok = in_range && ((tapmask[qm][i] >> tbit) & 1u) && tap < 31;
-        const char* real = second ? x2c + (r2off[qm][i] + (unsigned)(kc * 2)) : rptr[qm][i] + tap_off;
-        glds16(ok ? (const void*)real : zero_src, dst + i * 8192);
+        const unsigned base = second ? r2off[qm][i] : roff[qm][i];
+        blds16((tapmask[qm][i] & bit) ? base + add : kDmaOutOfRange, rs, dst + i * 8192);
       }
     } else {
       constexpr int qn = J == 2 ? 1 : 0;
-      const size_t wk = (size_t)(tap * a.Cin + kc) * 2;
+      const unsigned wk = (unsigned)(tap * a.Cin + kc) * 2u;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        glds16(in_range ? (const void*)(wptr[qn][i] + wk) : zero_src, dst + i * 8192);
+      for (int i = 0; i < 2; ++i) blds16(in_range ? woff[qn][i] + wk : kDmaOutOfRange, rs_w, dst + i * 8192);
     }
     if constexpr (J == 3) advance();
   };

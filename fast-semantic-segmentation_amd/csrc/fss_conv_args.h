@@ -46,6 +46,35 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
       : "memory", "m0");
 }
 
+// Buffer addressing of the LDS-DMA: a 128-bit resource (base, size) in SGPRs and one 32-bit byte
+// offset per lane.  A lane whose offset lies past the end of the buffer deposits ZEROS, which is
+// how padding taps, rows past M and K tiles past the last one are filled: no zero page and no
+// 64-bit address arithmetic per piece, one add and one select.  Every block describes only the
+// window of a tensor it can touch (its images / its rows / its weight rows), so the 32-bit
+// offsets hold for tensors of any size.
+typedef int fss_i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kDmaOutOfRange = 0xfffffff0u;     // past the end of every resource below
+__device__ __forceinline__ fss_i32x4 dma_resource(const void* base, unsigned long long bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  const unsigned n = bytes > 0xffffff00ull ? 0xffffff00u : (unsigned)bytes;
+  fss_i32x4 r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));   // stride 0: a raw buffer
+  r.z = __builtin_amdgcn_readfirstlane((int)n);
+  r.w = 0x00020000;                                                 // 32-bit raw data format
+  return r;
+}
+// One piece: 64 lanes x 16 bytes from base + voff (per lane) to the 1 KiB of LDS at lds_dst.
+__device__ __forceinline__ void blds16(unsigned voff, fss_i32x4 rsrc, unsigned lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %1, 0 offen lds"
+      :
+      : "v"(voff), "s"(rsrc), "s"(lds_dst)
+      : "memory", "m0");
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt out of range");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
