@@ -278,7 +278,7 @@ def main():
                        'frames_per_step_per_gpu': B, 'weights': 'synthetic seed 1234',
                        'parallelism': 'frames sharded over %d GPU(s)' % world,
                        'streams': cg.stream_choice},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel',
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (+ conv8_kernel, its 8-phase form)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak,
                          'mfma_per_product': mpp,

@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--dtype', default='bfloat16')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--layers', default=None)
+    ap.add_argument('--batches', default='', help='comma-separated batch sizes (default: the case\'s list)')
     ap.add_argument('--ksplit', action='store_true', help='split-K launches where they are faster (small batches)')
     args = ap.parse_args()
     from google.protobuf import text_format
@@ -42,6 +43,8 @@ def main():
         cfg = pipeline_pb2.PipelineConfig()
         with open(os.path.join(PKG, 'configs', cfg_file)) as f:
             text_format.Merge(f.read(), cfg)
+        if args.batches:
+            batches = [int(b) for b in args.batches.split(',')]
         for b in batches:
             g = G.reset_default_graph()
             _, model = model_builder.build(cfg.model, is_training=False)

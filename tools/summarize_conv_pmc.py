@@ -2,7 +2,7 @@
 tools/profile_round.sh: <out>/<tag>_conv_pmc.txt.
 
 bench.py ends with eager single-stream passes over the plan's launches (CompiledGraph.profile);
-the last `launches_per_step` conv_igemm_kernel dispatches of every counter run are the conv
+the last `launches_per_step` conv_igemm_kernel / conv8_kernel dispatches of every counter run are the conv
 layers of the final pass, in the order of <tag>_layers.txt.  Shown for the layers that take the
 most time: MFMA pipe busy share = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES (per-SIMD busy
 cycles over CU busy cycles x 4 SIMDs is how the hardware guide normalises it), LDS wait share,
@@ -21,7 +21,7 @@ def conv_rows(dirname, n):
     per = collections.defaultdict(list)
     with open(path) as f:
         for r in csv.DictReader(f):
-            if 'conv_igemm_kernel' in r['Kernel_Name']:
+            if 'conv_igemm_kernel' in r['Kernel_Name'] or 'conv8_kernel' in r['Kernel_Name']:
                 per[r['Counter_Name']].append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
     out = {}
     for name, rows in per.items():
@@ -49,7 +49,7 @@ def main():
         if os.path.isdir(d):
             c.update(conv_rows(d, n))
     order = sorted(range(n), key=lambda k: -layers[k][1])
-    lines = ['# conv_igemm_kernel, per layer (the %d slowest of %d), %s, %d frames per launch' % (
+    lines = ['# conv_igemm_kernel (configuration 35: conv8_kernel), per layer (the %d slowest of %d), %s, %d frames per launch' % (
         min(16, n), n, bench['dtype'], bench['config']['frames_per_step_per_gpu']),
         '# mfma = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES); lds_wait = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES;',
         '# tcp_stall = TCP_PENDING_STALL_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs); td_busy = TD_TD_BUSY / (GRBM_GUI_ACTIVE / 8 * 256 CUs)',

@@ -18,7 +18,7 @@ def conv_kb(dirname, counter, n):
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            if r['Counter_Name'] == counter and 'conv_igemm_kernel' in r['Kernel_Name']:
+            if r['Counter_Name'] == counter and ('conv_igemm_kernel' in r['Kernel_Name'] or 'conv8_kernel' in r['Kernel_Name']):
                 rows.append((int(r['Dispatch_Id']), float(r['Counter_Value'])))
     rows.sort()
     assert len(rows) >= n, (len(rows), n)
