@@ -508,6 +508,8 @@ AGREE_SHAPES = [
     (1, 65, 129, 64, 256, 1, 1, 1, True),      # pointwise + residual
     (3, 40, 52, 32, 72, 3, 2, 1, False),       # strided, cout not a multiple of the tiles
     (1, 29, 31, 256, 264, 1, 1, 1, True),      # cout a multiple of 8 only: widest vector path edge
+    (1, 65, 129, 192, 320, 3, 1, 2, True),     # 33 x 2 tiles of 256x256, an odd number of K tiles (27)
+    (1, 33, 65, 2048, 512, 1, 1, 1, False),    # long pointwise K (32 K tiles), two N tiles
 ]
 
 
