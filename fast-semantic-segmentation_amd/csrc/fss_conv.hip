@@ -648,7 +648,7 @@ conv_igemm_kernel(const ConvArgs a) {
         for (int r = 0; r < MMA::NREG; ++r)
           stage[(ti * FM + MMA::row_of(r, lg)) * SROW + j * FM + lrow] = acc[sl * TPS + ti][j][r] + bias;
     }
-    __syncthreads();
+    wave_lds_fence();   // the slab is private to this wave: LDS order within a wave suffices
     const int m_base = tile_m * BM + wm * WTM + sl * SLABR;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
@@ -698,7 +698,7 @@ conv_igemm_kernel(const ConvArgs a) {
         }
       }
     }
-    __syncthreads();
+    wave_lds_fence();   // the slab is private to this wave: LDS order within a wave suffices
   }
 }
 

@@ -378,7 +378,7 @@ conv8_kernel(const ConvArgs a) {
         for (int r = 0; r < NREG; ++r)
           stage_f[(ti * FM + 4 * lg + r) * SROW + j * FM + lrow] = acc[sl * TPS + ti][j][r] + bias;
     }
-    __syncthreads();
+    wave_lds_fence();   // the slab is private to this wave: LDS order within a wave suffices
     const int m_base = tile_m * kBM + wm * WTM + sl * SLABR;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
@@ -423,7 +423,7 @@ conv8_kernel(const ConvArgs a) {
         }
       }
     }
-    __syncthreads();
+    wave_lds_fence();   // the slab is private to this wave: LDS order within a wave suffices
   }
 }
 

@@ -75,6 +75,13 @@ __device__ __forceinline__ void blds16(unsigned voff, fss_i32x4 rsrc, unsigned l
       : "memory", "m0");
 }
 
+// Orders a wave's own LDS writes before its own later LDS reads (and the reverse): the LDS serves
+// one wave's instructions in issue order, so data staged and read back by the SAME wave needs no
+// workgroup barrier, only a point the compiler does not move memory operations across.
+__device__ __forceinline__ void wave_lds_fence() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt out of range");
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
