@@ -500,6 +500,42 @@ conv_igemm_kernel(const ConvArgs a) {
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) acc2[i][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Zoomed residual: per 16-pixel group i, the byte offset from zy of this lane's 8 channels
+    // (of the wave's first 32) in the top-left source pixel of its 2 x 2 neighbourhood; the
+    // offset is a multiple of 16, and its bits 0 / 1 say that the output row / column is odd,
+    // i.e. has a second source one row / column further.  32-bit arithmetic: the host checks
+    // that zy is below 4 GB.  zborder[i]: some lane of the wave has a pixel next to the frame
+    // border, whose sources come from the correction tensors (wave-uniform, rare).  zeven[i]:
+    // every lane's output row is even, so the second source row repeats the first.
+    const char* __restrict__ zyb = reinterpret_cast<const char*>(a.zy);
+    const unsigned zpix = (unsigned)a.Cout * (unsigned)sizeof(T), zrow = (unsigned)a.zW * zpix;
+    unsigned zo[MI] = {};
+    bool zborder[MI] = {}, zeven[MI] = {};
+    if (a.zy != nullptr) {
+      // (frame, row, column) of this lane's pixel in group 0 by division, in the further groups
+      // by stepping 16 pixels on (the output is at least 7 wide and high: at most 3 row wraps
+      // and one frame wrap per step); pixels past the end of the batch stand in for the last one
+      const int m0 = tile_m * BM + wm * WTM + lrow;
+      int f = (int)((unsigned)m0 / (unsigned)HoWo);
+      const int rem = m0 - f * HoWo;
+      int p = (int)((unsigned)rem / (unsigned)a.Wo), q = rem - p * a.Wo;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        if (i > 0) {
+          q += 16;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            if (q >= a.Wo) { q -= a.Wo; ++p; }
+          if (p >= a.Ho) { p -= a.Ho; ++f; }
+        }
+        const bool in = m0 + 16 * i < a.M;
+        const int fc = in ? f : a.N - 1, pc = in ? p : a.Ho - 1, qc = in ? q : a.Wo - 1;
+        zo[i] = ((unsigned)(fc * a.zH + (pc >> 1)) * zrow + (unsigned)(qc >> 1) * zpix +
+                 (unsigned)(n_base + 8 * lg) * (unsigned)sizeof(T)) | (unsigned)(pc & 1) | (unsigned)((qc & 1) << 1);
+        zborder[i] = __ballot(pc == 1 || pc == a.Ho - 2 || qc == 1 || qc == a.Wo - 2) != 0ull;
+        zeven[i] = __ballot(pc & 1) == 0ull;   // every lane's pixel has one source row
+      }
+    }
 #pragma unroll
     for (int s = 0; s < NI / 2; ++s) {
       const int c0 = n_base + 32 * s;
@@ -519,37 +555,68 @@ conv_igemm_kernel(const ConvArgs a) {
         f32x4 d0 = acc[i][2 * s], d1 = acc[i][2 * s + 1];
         if (a.zy != nullptr) {
           // residual = corrected x2 zoom of zy at this lane's pixel: the mean of 1, 2 or 4
-          // sources, formed branch-free as a quarter of the sum over the 2 x 2 neighbourhood
-          // with the indices clamped (a source counted twice or four times), so that the 4
-          // loads are independent and in flight together
-          const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
-          const int f = m / HoWo, rem = m - f * HoWo;
-          const int p = rem / a.Wo, q = rem - p * a.Wo;
+          // sources, formed branch-free as a quarter of (u0 + u1) + (u2 + u3) over the 2 x 2
+          // neighbourhood (a source counted twice or four times where a step is 0), so that the
+          // loads are independent and in flight together.  Where the whole wave has even rows,
+          // u2 = u0 and u3 = u1: half of (u0 + u1) is the same number, from two loads.
           uint4 u[4];
+          const unsigned zbase = (zo[i] & ~15u) + (unsigned)(64 * s);
+          const unsigned zdr = (zo[i] & 1u) ? zrow : 0u, zdc = (zo[i] & 2u) ? zpix : 0u;
+          const bool two = zeven[i] && !zborder[i];
+          if (two) {
+            u[0] = *reinterpret_cast<const uint4*>(zyb + zbase);
+            u[1] = *reinterpret_cast<const uint4*>(zyb + (zbase + zdc));
+            u[2] = u[3] = make_uint4(0u, 0u, 0u, 0u);
+          } else if (!zborder[i]) {
 #pragma unroll
-          for (int nb = 0; nb < 4; ++nb) {
-            const int zi = (p >> 1) + ((nb >> 1) & p), zj = (q >> 1) + (nb & q & 1);
-            const int rf = (p == 1 && zi == 1) ? 1 : (p == a.Ho - 2 && zi == a.zH - 2) ? 2 : 0;
-            const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
-            const T* src = reinterpret_cast<const T*>(a.zy) + (((size_t)f * a.zH + zi) * a.zW + zj) * a.Cout;
-            if (rf != 0 && cf == 0)
-              src = reinterpret_cast<const T*>(a.zytb) + (((size_t)(rf - 1) * a.N + f) * a.zW + zj) * a.Cout;
-            if (rf == 0 && cf != 0)
-              src = reinterpret_cast<const T*>(a.zylr) + (((size_t)(cf - 1) * a.N + f) * a.zH + zi) * a.Cout;
-            if (rf != 0 && cf != 0)
-              src = reinterpret_cast<const T*>(a.zycn) + ((size_t)((rf - 1) * 2 + (cf - 1)) * a.N + f) * a.Cout;
-            u[nb] = *reinterpret_cast<const uint4*>(src + c0 + 8 * lg);
+            for (int nb = 0; nb < 4; ++nb)
+              u[nb] = *reinterpret_cast<const uint4*>(zyb + (zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u)));
+          } else {
+            // next to the frame border a source row / column is replaced by its corrected copy
+            const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
+            const int f = m / HoWo, rem = m - f * HoWo;
+            const int p = rem / a.Wo, q = rem - p * a.Wo;
+            const unsigned lane_c = (unsigned)(c0 + 8 * lg) * (unsigned)sizeof(T);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+              const int zi = (p >> 1) + ((nb >> 1) & p), zj = (q >> 1) + (nb & q & 1);
+              const int rf = (p == 1 && zi == 1) ? 1 : (p == a.Ho - 2 && zi == a.zH - 2) ? 2 : 0;
+              const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
+              const char* base = zyb;
+              unsigned off = zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u);
+              if (rf != 0 && cf == 0) {
+                base = reinterpret_cast<const char*>(a.zytb);
+                off = (unsigned)(((rf - 1) * a.N + f) * a.zW + zj) * zpix + lane_c;
+              }
+              if (rf == 0 && cf != 0) {
+                base = reinterpret_cast<const char*>(a.zylr);
+                off = (unsigned)(((cf - 1) * a.N + f) * a.zH + zi) * zpix + lane_c;
+              }
+              if (rf != 0 && cf != 0) {
+                base = reinterpret_cast<const char*>(a.zycn);
+                off = (unsigned)(((rf - 1) * 2 + (cf - 1)) * a.N + f) * zpix + lane_c;
+              }
+              u[nb] = *reinterpret_cast<const uint4*>(base + off);
+            }
           }
-          float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
+          auto lo = [](unsigned v) { return __uint_as_float(v << 16); };
+          auto hi = [](unsigned v) { return __uint_as_float(v & 0xffff0000u); };
+          float r0[4], r1[4];
+          r0[0] = lo(u[0].x) + lo(u[1].x); r0[1] = hi(u[0].x) + hi(u[1].x);
+          r0[2] = lo(u[0].y) + lo(u[1].y); r0[3] = hi(u[0].y) + hi(u[1].y);
+          r1[0] = lo(u[0].z) + lo(u[1].z); r1[1] = hi(u[0].z) + hi(u[1].z);
+          r1[2] = lo(u[0].w) + lo(u[1].w); r1[3] = hi(u[0].w) + hi(u[1].w);
+          if (two) {
 #pragma unroll
-          for (int nb = 0; nb < 4; ++nb) {
-            r0[0] += __uint_as_float(u[nb].x << 16); r0[1] += __uint_as_float(u[nb].x & 0xffff0000u);
-            r0[2] += __uint_as_float(u[nb].y << 16); r0[3] += __uint_as_float(u[nb].y & 0xffff0000u);
-            r1[0] += __uint_as_float(u[nb].z << 16); r1[1] += __uint_as_float(u[nb].z & 0xffff0000u);
-            r1[2] += __uint_as_float(u[nb].w << 16); r1[3] += __uint_as_float(u[nb].w & 0xffff0000u);
+            for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.5f; d1[e] += r1[e] * 0.5f; }
+          } else {
+            r0[0] += lo(u[2].x) + lo(u[3].x); r0[1] += hi(u[2].x) + hi(u[3].x);
+            r0[2] += lo(u[2].y) + lo(u[3].y); r0[3] += hi(u[2].y) + hi(u[3].y);
+            r1[0] += lo(u[2].z) + lo(u[3].z); r1[1] += hi(u[2].z) + hi(u[3].z);
+            r1[2] += lo(u[2].w) + lo(u[3].w); r1[3] += hi(u[2].w) + hi(u[3].w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.25f; d1[e] += r1[e] * 0.25f; }
           }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.25f; d1[e] += r1[e] * 0.25f; }
         } else if (a.res != nullptr) {
           const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
           if (m < a.M) {
@@ -573,26 +640,38 @@ conv_igemm_kernel(const ConvArgs a) {
     // acc2[i][ct][q] = partial score of class 16 ct + 4 lg + q, pixel 16 i + lrow, over this
     // wave's channels: one staging plane per channel slice, summed below in a fixed order
     float* hs = reinterpret_cast<float*>(smem);
+    static_assert(kHeadMax == 20, "head staging: 16 classes from the first tile, 4 from the second");
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cls = ct * 16 + 4 * lg + q;
-          if (cls < kHeadMax) hs[((wn * BM) + wm * WTM + i * 16 + lrow) * kHeadMax + cls] = acc2[i][ct][q];
-        }
+    for (int i = 0; i < MI; ++i) {
+      // lane group lg holds classes 4 lg .. 4 lg + 3 (first tile) and 16 + 4 lg .. (second tile,
+      // of which only group 0's exist)
+      float* row = hs + ((wn * BM) + wm * WTM + i * 16 + lrow) * kHeadMax;
+      *reinterpret_cast<float4*>(row + 4 * lg) =
+          make_float4(acc2[i][0][0], acc2[i][0][1], acc2[i][0][2], acc2[i][0][3]);
+      if (lg == 0)
+        *reinterpret_cast<float4*>(row + 16) =
+            make_float4(acc2[i][1][0], acc2[i][1][1], acc2[i][1][2], acc2[i][1][3]);
+    }
     __syncthreads();
     TO* __restrict__ yh = reinterpret_cast<TO*>(a.y);
     const int nc = a.cout_head;
-    for (int e = tid; e < BM * nc; e += NT) {
-      const int px = e / nc, c = e - px * nc;
+    // one work item = 4 consecutive classes of one pixel, channel slices summed in index order
+    for (int e = tid; e < BM * (kHeadMax / 4); e += NT) {
+      const int px = e / (kHeadMax / 4), c = (e - px * (kHeadMax / 4)) * 4;
       const int m = tile_m * BM + px;
       if (m >= a.M) break;                   // px grows with e
-      float v = a.bias_head != nullptr ? a.bias_head[c] : 0.f;
+      float v[4];
 #pragma unroll
-      for (int w = 0; w < WAVES_N; ++w) v += hs[(w * BM + px) * kHeadMax + c];
-      ElemTraits<TO>::store(yh + (size_t)m * a.y_ld + c, v);
+      for (int k = 0; k < 4; ++k) v[k] = (a.bias_head != nullptr && c + k < nc) ? a.bias_head[c + k] : 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_N; ++w) {
+        const float4 t = *reinterpret_cast<const float4*>(hs + (w * BM + px) * kHeadMax + c);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+      }
+      TO* dst = yh + (size_t)m * a.y_ld + c;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (c + k < nc) ElemTraits<TO>::store(dst + k, v[k]);
     }
     return;
   }
@@ -997,6 +1076,8 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
     for (int i = 0; i < 4; ++i)
       FSS_REQUIRE(zoom_residual[i] != nullptr && ((uintptr_t)zoom_residual[i] & 15) == 0,
                   "zoom_residual: null or unaligned tensor");
+    FSS_REQUIRE((unsigned long long)d->n * zh * zw * d->cout * 2ull < 0xffffff00ull,
+                "zoom_residual: the half-resolution tensor must be below 4 GB");
     a.zy = zoom_residual[0]; a.zytb = zoom_residual[1]; a.zylr = zoom_residual[2]; a.zycn = zoom_residual[3];
     a.zH = zh; a.zW = zw;
   }

@@ -278,14 +278,17 @@ def test_dilated_conv_of_a_zoom_at_the_source_resolution(shape, dt):
             _close(out[sl], ref[sl], 2e-5, 'border')
 
 
-def test_head_conv_interpolates_its_residual_from_the_source_resolution():
+@pytest.mark.parametrize('n,zh,zw,cout', [(2, 6, 9, 128), (3, 4, 4, 128), (3, 9, 40, 256), (2, 5, 70, 128)])
+def test_head_conv_interpolates_its_residual_from_the_source_resolution(n, zh, zw, cout):
     """fss_conv2d_dual_head_nhwc with zoom_residual = {y, ytb, ylr, ycn}: the epilogue adds the
     corrected x2 zoom of y (border rows / columns from the three substitute tensors) exactly
-    as fss_zoom2_conv_commute would have stored it; checked against the same entry point fed
-    with that stored residual and against float64."""
+    as fss_zoom2_conv_commute would have stored it; checked against float64.  The shapes cover
+    the smallest legal map (7 pixels wide: several row wraps inside 16 consecutive pixels),
+    frames that end inside a wave's pixel group, and rows wide enough that whole groups lie on
+    one even output row (two sources instead of four)."""
     gu = _gu()
     rng = np.random.default_rng(41)
-    n, zh, zw, cin, cout, ncls = 2, 6, 9, 64, 128, 19
+    cin, ncls = 64, 19
     h, wd = 2 * zh - 1, 2 * zw - 1
     r16 = lambda *shape: gu.bf16_round(rng.normal(0, 1, shape).astype(np.float32))
     x, w = r16(n, h, wd, cin), gu.bf16_round(rng.normal(0, 0.1, (1, 1, cin, cout)).astype(np.float32))

@@ -23,6 +23,8 @@ SHAPES = {  # name: (h, w, cin, cout, k, stride, rate, residual)
     'b4_conv1': (33, 65, 2048, 512, 1, 1, 1, False),
     'b3_conv2': (33, 65, 256, 256, 3, 1, 4, False),
     'b1_conv3': (129, 257, 64, 256, 1, 1, 1, True),
+    'b3_conv3': (65, 129, 256, 1024, 1, 1, 1, True),
+    'b3_conv1': (65, 129, 1024, 256, 1, 1, 1, False),
     'cff1_conv': (129, 257, 256, 256, 1, 1, 1, True),
     'branch0': (1025, 2049, 8, 64, 3, 2, 1, False),
 }

@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'conv_tuned.json'))
     ap.add_argument('--fresh', action='store_true', help='ignore the shipped table')
+    ap.add_argument('--drop', default='', help='time again the shapes whose table key contains this text')
     args = ap.parse_args()
     from google.protobuf import text_format
     from protos import pipeline_pb2
@@ -28,6 +29,10 @@ def main():
     import torch
     if args.fresh:
         plan.CompiledGraph._TUNE_CACHE = {}
+    if args.drop:
+        plan.CompiledGraph._tune_load()
+        for key in [k for k in plan.CompiledGraph._TUNE_CACHE if args.drop in k]:
+            del plan.CompiledGraph._TUNE_CACHE[key]
     jobs = []
     for name, (cfg_file, in_shape, pad_shape, batches) in CASES.items():
         for dtype, edges in (('bfloat16', (16, 32)), ('float32', (32, 16)), ('float32x3', (16, 32))):
