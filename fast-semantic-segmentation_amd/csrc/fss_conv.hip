@@ -760,7 +760,7 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
           for (int e = 0; e < VW; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
           if constexpr (sizeof(TO) == 4) {
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            store16_nt(dst, __float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
           } else {
             store16_nt(dst, pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
                        pack_bf16x2(v[6], v[7]));

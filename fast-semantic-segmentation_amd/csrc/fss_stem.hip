@@ -82,12 +82,18 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
     const int r = tid / a.KW, s = tid - r * a.KW;
     tapoff[tid] = tid < a.KH * a.KW ? (r * a.dil * a.PW + s * a.dil) : 0;
   }
-  {  // LDS row rho = 16*nj + 4*gg + q holds output channel gg*4*NJ + 4*nj + q, so that
-     // the 4*NJ accumulator values of lane group gg are consecutive channels
+  // Which output channel accumulator value q of tile nj is in lane group gg (= LDS weight row
+  // 16*nj + 4*gg + q).  2-byte outputs: gg*4*NJ + 4*nj + q, so that the 4*NJ values of a lane are
+  // consecutive channels (one or two 16-byte stores per lane).  Float outputs: the natural order
+  // 16*nj + 4*gg + q, so that one store instruction writes, per pixel, the 64 consecutive bytes of
+  // the four lane groups instead of four 16-byte pieces 4*NJ*4 bytes apart.
+  constexpr bool NATURAL = sizeof(TO) == 4;
+  auto chan_of = [](int nj, int gg, int q) { return NATURAL ? 16 * nj + 4 * gg + q : gg * (4 * NJ) + 4 * nj + q; };
+  {
     const int cpr = a.K4pad * ES / 16;
     for (int idx = tid; idx < NJ * 16 * cpr; idx += 256) {
       const int rho = idx / cpr, c = idx - rho * cpr;
-      const int co = ((rho >> 2) & 3) * (4 * NJ) + 4 * (rho >> 4) + (rho & 3);
+      const int co = chan_of(rho >> 4, (rho >> 2) & 3, rho & 3);
       *reinterpret_cast<uint4*>(wl + rho * WROW + c * 16) = *reinterpret_cast<const uint4*>(
           reinterpret_cast<const char*>(a.w) + ((size_t)co * a.K4pad * ES + c * 16));
       if constexpr (SPLIT)
@@ -100,13 +106,14 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int co = g * (4 * NJ) + 4 * nj + q;
+      const int co = chan_of(nj, g, q);
       bias[nj][q] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
     }
   const float act_lo = a.act == FSS_ACT_NONE ? -INFINITY : 0.f;
   const float act_hi = a.act == FSS_ACT_RELU6 ? 6.f : INFINITY;
   // whole-lane vector stores need every lane's piece 16-byte aligned
-  const bool vec_ok = (a.y_ld * (int)sizeof(TO)) % 16 == 0 && g * (4 * NJ) + 4 * NJ <= a.Cout;
+  const bool vec_ok = (a.y_ld * (int)sizeof(TO)) % 16 == 0 &&
+                      (NATURAL ? 16 * NJ <= a.Cout : g * (4 * NJ) + 4 * NJ <= a.Cout);
 
   // this wave's four 16-pixel groups: output rows 2*wave, 2*wave+1, columns 0-15 / 16-31.
   // base: patch pixel of tap (0,0) (clamped for columns past the tile, whose results are
@@ -116,7 +123,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   for (int mt = 0; mt < 4; ++mt) {
     const int orow = 2 * wave + (mt >> 1), ocol = (mt & 1) * 16 + p;
     base[mt] = (orow * a.stride) * a.PW + min(ocol, a.TW - 1) * a.stride;
-    ooff[mt] = (orow * a.Wo + ocol) * a.y_ld + g * (4 * NJ);
+    ooff[mt] = (orow * a.Wo + ocol) * a.y_ld + (NATURAL ? 4 * g : g * (4 * NJ));
   }
 
   const int tiles_per_img = a.tiles_x * a.tiles_y;
@@ -353,7 +360,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
       }
     }
 
-    // lane (p, g) holds channels g*4*NJ .. +4*NJ-1 of pixel p of each group
+    // lane (p, g) holds channels chan_of(nj, g, 0..3) of pixel p of each group
     TO* __restrict__ ytile = reinterpret_cast<TO*>(a.y) +
                             (((size_t)now.n * a.Ho + now.oh0) * a.Wo + now.ow0) * a.y_ld;
     const int rows_left = a.Ho - now.oh0, cols_left = min(a.TW, a.Wo - now.ow0);
@@ -371,8 +378,8 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
         if constexpr (sizeof(TO) == 4) {
 #pragma unroll
           for (int nj = 0; nj < NJ; ++nj)
-            *reinterpret_cast<float4*>(dst + 4 * nj) =
-                make_float4(v[4 * nj], v[4 * nj + 1], v[4 * nj + 2], v[4 * nj + 3]);
+            store16_nt(dst + 16 * nj, __float_as_uint(v[4 * nj]), __float_as_uint(v[4 * nj + 1]),
+                       __float_as_uint(v[4 * nj + 2]), __float_as_uint(v[4 * nj + 3]));
         } else {
           unsigned o[2 * NJ];
 #pragma unroll
@@ -390,8 +397,11 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 4 * NJ; ++e)
-          if (g * (4 * NJ) + e < a.Cout) ElemTraits<TO>::store(dst + e, v[e]);
+        for (int e = 0; e < 4 * NJ; ++e) {
+          // dst points at the lane's first channel; element e sits (channel - first channel) on
+          const int off = chan_of(e >> 2, g, e & 3) - chan_of(0, g, 0);
+          if (chan_of(e >> 2, g, e & 3) < a.Cout) ElemTraits<TO>::store(dst + off, v[e]);
+        }
       }
     }
   }
