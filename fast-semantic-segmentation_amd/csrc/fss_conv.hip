@@ -441,7 +441,7 @@ conv_igemm_kernel(const ConvArgs a) {
       // pair (2q, 2q + 1), q = LG * step + lg: 8 floats of A (split here), and the
       // pre-split weights, whose rows hold per 8 k values their 8 bf16 high parts (chunk 2q)
       // followed by their 8 bf16 remainders (chunk 2q + 1)
-      static_assert(KSTEPS % 2 == 0 && !HEAD, "split mode pairs the chunks of a tile row");
+      static_assert(KSTEPS % 2 == 0, "split mode pairs the chunks of a tile row");
 #pragma unroll
       for (int s = 0; s < KSTEPS / 2; ++s) {
         const int o0 = ((2 * (LG * s + lg)) ^ swz) * 16, o1 = ((2 * (LG * s + lg) + 1) ^ swz) * 16;
@@ -458,7 +458,10 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NI; ++j) MMA::run3(acc[i][j], ahi[i], alo[i], bhi[j], blo[j]);
+          for (int j = 0; j < NI; ++j) {
+            if constexpr (HEAD) MMA::run3(acc[i][j], bhi[j], blo[j], ahi[i], alo[i]);
+            else MMA::run3(acc[i][j], ahi[i], alo[i], bhi[j], blo[j]);
+          }
       }
     } else {
 #pragma unroll
@@ -487,13 +490,39 @@ conv_igemm_kernel(const ConvArgs a) {
     // tile, tile rows 16 j + 4 lg + q = channels 32 (j >> 1) + 8 lg + 4 (j & 1) + q (the weight
     // rows were fetched in that order).  Second product, per 32 channels (two D tiles): k index
     // 8 lg + e of both operands = channel 32 s + 8 lg + e.
-    static_assert(FM == 16 && sizeof(T) == 2 && NI % 2 == 0, "head epilogue: 16x16x32 bf16 tiles");
+    static_assert(FM == 16 && NI % 2 == 0 && (sizeof(T) == 2 || MMA::PAIRED),
+                  "head epilogue: 16x16x32 bf16 tiles (bf16 tensors, or float tensors in the split mode)");
+    // Split mode: residuals are float (two 16-byte loads per 8 channels), the activated values
+    // are split like every other activation and the classifier weights arrive as two bf16
+    // planes [32][cout] (high parts, then remainders): three MFMAs per step again.
+    constexpr bool SPLIT = MMA::PAIRED;
+    constexpr unsigned ESZ = (unsigned)sizeof(T);
+    // 8 consecutive channels as they lie in memory, and as floats
+    struct Raw8 { uint4 a, b; };
+    auto raw8 = [](const char* p) {
+      Raw8 r;
+      r.a = *reinterpret_cast<const uint4*>(p);
+      if constexpr (SPLIT) r.b = *reinterpret_cast<const uint4*>(p + 16);
+      else r.b = r.a;
+      return r;
+    };
+    auto floats8 = [](const Raw8& r, float (&f)[8]) {
+      if constexpr (SPLIT) {
+        f[0] = __uint_as_float(r.a.x); f[1] = __uint_as_float(r.a.y); f[2] = __uint_as_float(r.a.z); f[3] = __uint_as_float(r.a.w);
+        f[4] = __uint_as_float(r.b.x); f[5] = __uint_as_float(r.b.y); f[6] = __uint_as_float(r.b.z); f[7] = __uint_as_float(r.b.w);
+      } else {
+        f[0] = __uint_as_float(r.a.x << 16); f[1] = __uint_as_float(r.a.x & 0xffff0000u);
+        f[2] = __uint_as_float(r.a.y << 16); f[3] = __uint_as_float(r.a.y & 0xffff0000u);
+        f[4] = __uint_as_float(r.a.z << 16); f[5] = __uint_as_float(r.a.z & 0xffff0000u);
+        f[6] = __uint_as_float(r.a.w << 16); f[7] = __uint_as_float(r.a.w & 0xffff0000u);
+      }
+    };
     static_assert(WAVES_N * BM * kHeadMax * 4 <= NSTAGE * STAGE_BYTES, "head staging does not fit");
     wait_vmcnt<0>();
     __syncthreads();                         // everyone is done with the ring
     const float act_lo = a.act == FSS_ACT_NONE ? -INFINITY : 0.f;
     const float act_hi = a.act == FSS_ACT_RELU6 ? 6.f : INFINITY;
-    const T* __restrict__ wh = reinterpret_cast<const T*>(a.w_head);
+    const bf16_t* __restrict__ wh = reinterpret_cast<const bf16_t*>(a.w_head);
     const int n_base = tile_n * BN + wn * WTN;
     f32x4 acc2[MI][2];
 #pragma unroll
@@ -508,7 +537,7 @@ conv_igemm_kernel(const ConvArgs a) {
     // border, whose sources come from the correction tensors (wave-uniform, rare).  zeven[i]:
     // every lane's output row is even, so the second source row repeats the first.
     const char* __restrict__ zyb = reinterpret_cast<const char*>(a.zy);
-    const unsigned zpix = (unsigned)a.Cout * (unsigned)sizeof(T), zrow = (unsigned)a.zW * zpix;
+    const unsigned zpix = (unsigned)a.Cout * ESZ, zrow = (unsigned)a.zW * zpix;
     unsigned zo[MI] = {};
     bool zborder[MI] = {}, zeven[MI] = {};
     if (a.zy != nullptr) {
@@ -531,7 +560,7 @@ conv_igemm_kernel(const ConvArgs a) {
         const bool in = m0 + 16 * i < a.M;
         const int fc = in ? f : a.N - 1, pc = in ? p : a.Ho - 1, qc = in ? q : a.Wo - 1;
         zo[i] = ((unsigned)(fc * a.zH + (pc >> 1)) * zrow + (unsigned)(qc >> 1) * zpix +
-                 (unsigned)(n_base + 8 * lg) * (unsigned)sizeof(T)) | (unsigned)(pc & 1) | (unsigned)((qc & 1) << 1);
+                 (unsigned)(n_base + 8 * lg) * ESZ) | (unsigned)(pc & 1) | (unsigned)((qc & 1) << 1);
         zborder[i] = __ballot(pc == 1 || pc == a.Ho - 2 || qc == 1 || qc == a.Wo - 2) != 0ull;
         zeven[i] = __ballot(pc & 1) == 0ull;   // every lane's pixel has one source row
       }
@@ -540,10 +569,12 @@ conv_igemm_kernel(const ConvArgs a) {
     for (int s = 0; s < NI / 2; ++s) {
       const int c0 = n_base + 32 * s;
       if (c0 >= a.Cout) break;               // wave-uniform: Cout is a multiple of 32
-      uint4 wa[2];
+      uint4 wa[2], wal[SPLIT ? 2 : 1];
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         wa[ct] = *reinterpret_cast<const uint4*>(wh + (size_t)(ct * 16 + lrow) * a.Cout + c0 + 8 * lg);
+        if constexpr (SPLIT)
+          wal[ct] = *reinterpret_cast<const uint4*>(wh + (size_t)(32 + ct * 16 + lrow) * a.Cout + c0 + 8 * lg);
       }
       float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
       if (a.bias != nullptr) {
@@ -559,24 +590,24 @@ conv_igemm_kernel(const ConvArgs a) {
           // neighbourhood (a source counted twice or four times where a step is 0), so that the
           // loads are independent and in flight together.  Where the whole wave has even rows,
           // u2 = u0 and u3 = u1: half of (u0 + u1) is the same number, from two loads.
-          uint4 u[4];
-          const unsigned zbase = (zo[i] & ~15u) + (unsigned)(64 * s);
+          Raw8 u[4];
+          const unsigned zbase = (zo[i] & ~15u) + (unsigned)(32 * s) * ESZ;
           const unsigned zdr = (zo[i] & 1u) ? zrow : 0u, zdc = (zo[i] & 2u) ? zpix : 0u;
           const bool two = zeven[i] && !zborder[i];
           if (two) {
-            u[0] = *reinterpret_cast<const uint4*>(zyb + zbase);
-            u[1] = *reinterpret_cast<const uint4*>(zyb + (zbase + zdc));
-            u[2] = u[3] = make_uint4(0u, 0u, 0u, 0u);
+            u[0] = raw8(zyb + zbase);
+            u[1] = raw8(zyb + (zbase + zdc));
+            u[2] = u[3] = u[0];                  // not used
           } else if (!zborder[i]) {
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
-              u[nb] = *reinterpret_cast<const uint4*>(zyb + (zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u)));
+              u[nb] = raw8(zyb + (zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u)));
           } else {
             // next to the frame border a source row / column is replaced by its corrected copy
             const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
             const int f = m / HoWo, rem = m - f * HoWo;
             const int p = rem / a.Wo, q = rem - p * a.Wo;
-            const unsigned lane_c = (unsigned)(c0 + 8 * lg) * (unsigned)sizeof(T);
+            const unsigned lane_c = (unsigned)(c0 + 8 * lg) * ESZ;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
               const int zi = (p >> 1) + ((nb >> 1) & p), zj = (q >> 1) + (nb & q & 1);
@@ -596,45 +627,50 @@ conv_igemm_kernel(const ConvArgs a) {
                 base = reinterpret_cast<const char*>(a.zycn);
                 off = (unsigned)(((rf - 1) * 2 + (cf - 1)) * a.N + f) * zpix + lane_c;
               }
-              u[nb] = *reinterpret_cast<const uint4*>(base + off);
+              u[nb] = raw8(base + off);
             }
           }
-          auto lo = [](unsigned v) { return __uint_as_float(v << 16); };
-          auto hi = [](unsigned v) { return __uint_as_float(v & 0xffff0000u); };
-          float r0[4], r1[4];
-          r0[0] = lo(u[0].x) + lo(u[1].x); r0[1] = hi(u[0].x) + hi(u[1].x);
-          r0[2] = lo(u[0].y) + lo(u[1].y); r0[3] = hi(u[0].y) + hi(u[1].y);
-          r1[0] = lo(u[0].z) + lo(u[1].z); r1[1] = hi(u[0].z) + hi(u[1].z);
-          r1[2] = lo(u[0].w) + lo(u[1].w); r1[3] = hi(u[0].w) + hi(u[1].w);
+          float f0[8], f1[8], r8[8];
+          floats8(u[0], f0);
+          floats8(u[1], f1);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) r8[e] = f0[e] + f1[e];
           if (two) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.5f; d1[e] += r1[e] * 0.5f; }
+            for (int e = 0; e < 4; ++e) { d0[e] += r8[e] * 0.5f; d1[e] += r8[4 + e] * 0.5f; }
           } else {
-            r0[0] += lo(u[2].x) + lo(u[3].x); r0[1] += hi(u[2].x) + hi(u[3].x);
-            r0[2] += lo(u[2].y) + lo(u[3].y); r0[3] += hi(u[2].y) + hi(u[3].y);
-            r1[0] += lo(u[2].z) + lo(u[3].z); r1[1] += hi(u[2].z) + hi(u[3].z);
-            r1[2] += lo(u[2].w) + lo(u[3].w); r1[3] += hi(u[2].w) + hi(u[3].w);
+            floats8(u[2], f0);
+            floats8(u[3], f1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.25f; d1[e] += r1[e] * 0.25f; }
+            for (int e = 0; e < 8; ++e) r8[e] += f0[e] + f1[e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d0[e] += r8[e] * 0.25f; d1[e] += r8[4 + e] * 0.25f; }
           }
         } else if (a.res != nullptr) {
           const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
           if (m < a.M) {
-            const uint4 rv = *reinterpret_cast<const uint4*>(
-                reinterpret_cast<const T*>(a.res) + (size_t)m * a.res_ld + c0 + 8 * lg);
-            d0[0] += __uint_as_float(rv.x << 16); d0[1] += __uint_as_float(rv.x & 0xffff0000u);
-            d0[2] += __uint_as_float(rv.y << 16); d0[3] += __uint_as_float(rv.y & 0xffff0000u);
-            d1[0] += __uint_as_float(rv.z << 16); d1[1] += __uint_as_float(rv.z & 0xffff0000u);
-            d1[2] += __uint_as_float(rv.w << 16); d1[3] += __uint_as_float(rv.w & 0xffff0000u);
+            float f0[8];
+            floats8(raw8(reinterpret_cast<const char*>(a.res) + ((size_t)m * a.res_ld + c0 + 8 * lg) * ESZ), f0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d0[e] += f0[e]; d1[e] += f0[4 + e]; }
           }
         }
         auto cl = [&](float v) { return fminf(fmaxf(v, act_lo), act_hi); };
-        const uint4 fb = make_uint4(pack_bf16x2(cl(d0[0] + b0.x), cl(d0[1] + b0.y)),
-                                    pack_bf16x2(cl(d0[2] + b0.z), cl(d0[3] + b0.w)),
-                                    pack_bf16x2(cl(d1[0] + b1.x), cl(d1[1] + b1.y)),
-                                    pack_bf16x2(cl(d1[2] + b1.z), cl(d1[3] + b1.w)));
+        const float v8[8] = {cl(d0[0] + b0.x), cl(d0[1] + b0.y), cl(d0[2] + b0.z), cl(d0[3] + b0.w),
+                             cl(d1[0] + b1.x), cl(d1[1] + b1.y), cl(d1[2] + b1.z), cl(d1[3] + b1.w)};
+        if constexpr (SPLIT) {
+          uint4 fh, fl;
+          split8(make_uint4(__float_as_uint(v8[0]), __float_as_uint(v8[1]), __float_as_uint(v8[2]), __float_as_uint(v8[3])),
+                 make_uint4(__float_as_uint(v8[4]), __float_as_uint(v8[5]), __float_as_uint(v8[6]), __float_as_uint(v8[7])),
+                 fh, fl);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) MMA::run(acc2[i][ct], wa[ct], fb);
+          for (int ct = 0; ct < 2; ++ct) MMA::run3(acc2[i][ct], wa[ct], wal[ct], fh, fl);
+        } else {
+          const uint4 fb = make_uint4(pack_bf16x2(v8[0], v8[1]), pack_bf16x2(v8[2], v8[3]),
+                                      pack_bf16x2(v8[4], v8[5]), pack_bf16x2(v8[6], v8[7]));
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) MMA::run(acc2[i][ct], wa[ct], fb);
+        }
       }
     }
     // acc2[i][ct][q] = partial score of class 16 ct + 4 lg + q, pixel 16 i + lrow, over this
@@ -915,29 +951,32 @@ static int dispatch_conv(ConvArgs& a, int config, hipStream_t stream) {
 
 // Classifier-head form: the 16x16x32 configurations whose N tile holds every output channel
 // of the layer (BN >= 128 and cout <= BN); -1 = this configuration cannot.
-template <int BM, int BN, int WM, int WN, int BKB, int NS, int FM>
+template <typename T, int BM, int BN, int WM, int WN, int BKB, int NS, int FM>
 static int launch_conv_head(ConvArgs& a, hipStream_t stream) {
-  if constexpr (FM == 16 && BN >= 128) {
+  // split mode: only the configurations with an even number of k steps per tile
+  if constexpr (FM == 16 && BN >= 128 && (std::is_same<T, bf16_t>::value || (BKB / 64) % 2 == 0)) {
     if (a.Cout > BN) return -1;
-    return launch_conv_impl<bf16_t, float, BM, BN, WM, WN, BKB, NS, FM, true, true>(a, stream);
+    return launch_conv_impl<T, float, BM, BN, WM, WN, BKB, NS, FM, true, true>(a, stream);
   } else {
     return -1;
   }
 }
 
+template <typename T>
 static int dispatch_conv_head(ConvArgs& a, int config, hipStream_t stream) {
   if (config == 0) config = a.Cout > 128 ? 28 : 29;
   if (config == kConv8Config) config = 28;
   int rc = -1;
   switch (config) {
 #define FSS_CASE(ID, BM, BN, WM, WN, BKB, NS, FM) \
-  case ID: rc = launch_conv_head<BM, BN, WM, WN, BKB, NS, FM>(a, stream); break;
+  case ID: rc = launch_conv_head<T, BM, BN, WM, WN, BKB, NS, FM>(a, stream); break;
     FSS_CONV_CONFIGS(FSS_CASE)
 #undef FSS_CASE
     default: break;
   }
   if (rc < 0) {
-    set_error("fss_conv2d_dual_head_nhwc: needs a 16x16x32 configuration with an N tile >= cout");
+    set_error("fss_conv2d_dual_head_nhwc: needs a 16x16x32 configuration with an N tile >= cout "
+              "(FSS_F32_BF16X3: and 128 bytes of K per tile row)");
     return 2;
   }
   return rc;
@@ -1054,7 +1093,9 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
                                          const void* w_head, const float* bias_head, int cout_head,
                                          float* y_head, int y_head_ld, void* stream) {
   FSS_REQUIRE(d && w_head && y_head, "null argument");
-  FSS_REQUIRE(d->in_dtype == FSS_BF16, "the classifier-head form takes bf16 activations");
+  FSS_REQUIRE(d->in_dtype == FSS_BF16 || d->in_dtype == FSS_F32_BF16X3,
+              "the classifier-head form takes bf16 activations, or float ones in the FSS_F32_BF16X3 mode");
+  const unsigned long long esz = d->in_dtype == FSS_BF16 ? 2ull : 4ull;
   FSS_REQUIRE(cout_head > 0 && cout_head <= kHeadMax, "cout_head out of range");
   FSS_REQUIRE(y_head_ld >= cout_head, "y_head_ld < cout_head");
   FSS_REQUIRE(d->cout % 32 == 0 && d->cout <= 256, "cout must be a multiple of 32, at most 256");
@@ -1076,14 +1117,15 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
     for (int i = 0; i < 4; ++i)
       FSS_REQUIRE(zoom_residual[i] != nullptr && ((uintptr_t)zoom_residual[i] & 15) == 0,
                   "zoom_residual: null or unaligned tensor");
-    FSS_REQUIRE((unsigned long long)d->n * zh * zw * d->cout * 2ull < 0xffffff00ull,
+    FSS_REQUIRE((unsigned long long)d->n * zh * zw * d->cout * esz < 0xffffff00ull,
                 "zoom_residual: the half-resolution tensor must be below 4 GB");
     a.zy = zoom_residual[0]; a.zytb = zoom_residual[1]; a.zylr = zoom_residual[2]; a.zycn = zoom_residual[3];
     a.zH = zh; a.zW = zw;
   }
   a.y = y_head; a.y_ld = y_head_ld;
   a.w_head = w_head; a.bias_head = bias_head; a.cout_head = cout_head;
-  return dispatch_conv_head(a, d->config, (hipStream_t)stream);
+  if (d->in_dtype == FSS_F32_BF16X3) return dispatch_conv_head<f32s_t>(a, d->config, (hipStream_t)stream);
+  return dispatch_conv_head<bf16_t>(a, d->config, (hipStream_t)stream);
 }
 
 // Second launch of the split-K form: y = act(sum over slabs + bias + residual), 4 channels a thread,

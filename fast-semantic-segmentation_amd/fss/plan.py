@@ -512,7 +512,9 @@ class CompiledGraph(object):
         """The 1x1 classifier (a convolution with biases, no normalisation or activation, at
         most 20 classes) that is the only consumer of `result`, when it can run in the
         epilogue of the convolution producing `result` (fss_conv2d_dual_head_nhwc)."""
-        if not self.fuse_head or dt != 'bf16' or self.mfma_edge != 16 or cout % 32 or cout > 256:
+        if not self.fuse_head or self.mfma_edge != 16 or cout % 32 or cout > 256:
+            return None
+        if dt != 'bf16' and not (dt == 'f32' and self.split):
             return None
         c = self._only_consumer(result, 'conv2d')
         if c is None or c in self.dual or self._dual_partner(c) is not None:
@@ -530,10 +532,18 @@ class CompiledGraph(object):
         sc, bh = self._fold_bn(head.attrs, ncls)
         Wh = np.zeros((32, cout), np.float32)
         Wh[:ncls] = (self.weights[head.attrs['weights']].astype(np.float64) * sc).reshape(cout, ncls).T
-        whdev = torch.from_numpy(f32_to_bf16_bits(Wh).view(np.int16)).to(self.device)
+        esz = _ESZ[x.dt]
+        if x.dt == 'bf16':
+            wh_bits = f32_to_bf16_bits(Wh)
+        else:
+            # float32x3: bf16 high parts of the float weights, then the bf16 remainders
+            hi = f32_to_bf16_bits(Wh)
+            hi_f = (hi.astype(np.uint32) << 16).view(np.float32)
+            wh_bits = np.concatenate([hi, f32_to_bf16_bits(Wh - hi_f)], axis=0)
+        whdev = torch.from_numpy(np.ascontiguousarray(wh_bits).view(np.int16)).to(self.device)
         self.keepalive.append(whdev)
         bhdev = self._dev_f32(bh)
-        self.param_bytes += cout * ncls * 2
+        self.param_bytes += cout * ncls * esz
         pc_out = (ncls + 3) // 4 * 4       # as the unfused classifier: float4-readable pixels
         out = Val(torch.zeros((n, ho, wo, pc_out), dtype=torch.float32, device=self.device),
                   head.shape, 'f32', phys_c=pc_out)
@@ -541,7 +551,7 @@ class CompiledGraph(object):
         self.fused.add(head)
         nbytes = ((x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] + n * ho * wo * cin2 + cout * k
                    + cout * ncls + (n * ho * wo * cout if res is not None else 0)
-                   + (sum(int(np.prod(v.shape)) for v in zres) if zres else 0)) * 2
+                   + (sum(int(np.prod(v.shape)) for v in zres) if zres else 0)) * esz
                   + n * ho * wo * ncls * 4)
         zptrs = (ctypes.c_void_p * 4)(*[v.ptr for v in zres]) if zres else None
         self._emit('conv', name + '+' + head.attrs['weights'].rsplit('/', 2)[-2],

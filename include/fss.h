@@ -155,12 +155,16 @@ int fss_conv2d_dual_nhwc(const fss_conv_desc* desc, const void* x, const void* x
  * pixel leave the kernel (float32, pixel stride y_head_ld).  Replaces the last cascade
  * feature fusion + the `Predictions` slim.conv2d of architectures/icnet_architecture.py:
  * 131-142,238-252 (the classifier applied before the x2 upsampling, which commutes with a
- * 1x1 convolution).  bf16 activations only; cin (and cin2) multiples of 64; cout a multiple
- * of 32 and <= 256; cout_head <= 20; w_head: bf16 [32][cout], rows >= cout_head zero;
- * desc->config: 0 or a 16x16-MFMA configuration whose block columns >= cout;
- * `residual`: bf16 [pixels][cout] with pixel stride desc->res_ld, or NULL.
+ * 1x1 convolution).  desc->in_dtype FSS_BF16 (the rounding to bf16 in the formula above is
+ * that mode's) or FSS_F32_BF16X3 (float tensors, nothing rounded: the activated values are
+ * split like every other activation); cin (and cin2) multiples of 64; cout a multiple
+ * of 32 and <= 256; cout_head <= 20; w_head: bf16 [32][cout], rows >= cout_head zero
+ * (FSS_F32_BF16X3: [2][32][cout], the bf16 high parts of the float weights, then their bf16
+ * remainders); desc->config: 0 or a 16x16-MFMA configuration whose block columns >= cout
+ * (FSS_F32_BF16X3: with 128 bytes of K per tile row);
+ * `residual`: [pixels][cout] of the activation type with pixel stride desc->res_ld, or NULL.
  * `zoom_residual` (or NULL): the residual given at half resolution, as the four tensors
- * {y, ytb, ylr, ycn} of fss_zoom2_conv_commute (bf16, cout channels, y: [n,zh,zw,cout],
+ * {y, ytb, ylr, ycn} of fss_zoom2_conv_commute (activation type, cout channels, y: [n,zh,zw,cout],
  * ytb: [2n,1,zw,cout], ylr: [2n,zh,1,cout], ycn: [4n,1,1,cout]) and
  * interpolated in the epilogue instead of being read from a zoomed copy; ho = 2 zh - 1,
  * wo = 2 zw - 1.

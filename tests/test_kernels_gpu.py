@@ -207,31 +207,35 @@ def test_conv2d_dual_is_the_sum_of_two_convolutions(dt):
             assert np.array_equal(out, first), 'config %d differs inside its shape class' % cfg
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'f32x3'])
 @pytest.mark.parametrize('cout,cin2,with_res', [(256, 64, False), (128, 0, True), (96, 128, False)])
-def test_conv2d_head_is_conv_then_classifier(cout, cin2, with_res):
-    """fss_conv2d_dual_head_nhwc = the two-input convolution, rounded to bfloat16 as the
-    unfused plan stores it, followed by the 1x1 classifier, against the oracle in float64;
-    every configuration that can hold the layer must agree to float summation order, the
-    others must refuse."""
+def test_conv2d_head_is_conv_then_classifier(cout, cin2, with_res, dt):
+    """fss_conv2d_dual_head_nhwc = the two-input convolution (bf16: rounded to bfloat16 as the
+    unfused plan stores it; float32x3: not rounded), followed by the 1x1 classifier, against
+    the oracle in float64; every configuration that can hold the layer must agree to float
+    summation order, the others must refuse."""
     gu, L = _gu(), _lib()
     rng = np.random.default_rng(22)
     n, h, wd, cin, ncls = 2, 19, 31, 64, 19
-    x = gu.bf16_round(rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32))
-    w = gu.bf16_round(rng.normal(0, 0.05, (3, 3, cin, cout)).astype(np.float32))
+    rnd = gu.bf16_round if dt == 'bf16' else (lambda v: v)
+    x = rnd(rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32))
+    w = rnd(rng.normal(0, 0.05, (3, 3, cin, cout)).astype(np.float32))
     x2 = w2 = None
     conv = O.conv2d(x, w, 1, 2, 'SAME', np.float64)
     if cin2:
-        x2 = gu.bf16_round(rng.normal(0, 1, (n, h, wd, cin2)).astype(np.float32))
-        w2 = gu.bf16_round(rng.normal(0, 0.1, (1, 1, cin2, cout)).astype(np.float32))
+        x2 = rnd(rng.normal(0, 1, (n, h, wd, cin2)).astype(np.float32))
+        w2 = rnd(rng.normal(0, 0.1, (1, 1, cin2, cout)).astype(np.float32))
         conv = conv + O.conv2d(x2, w2, 1, 1, 'SAME', np.float64)
     bias = rng.normal(0, 1, cout).astype(np.float32)
-    w_head = gu.bf16_round(rng.normal(0, 0.1, (cout, ncls)).astype(np.float32))
+    w_head = rnd(rng.normal(0, 0.1, (cout, ncls)).astype(np.float32))
     b_head = rng.normal(0, 1, ncls).astype(np.float32)
     res = None
     if with_res:
-        res = gu.bf16_round(rng.normal(0, 1, (n, h, wd, cout)).astype(np.float32))
+        res = rnd(rng.normal(0, 1, (n, h, wd, cout)).astype(np.float32))
         conv = conv + res
-    act = gu.bf16_round(O.relu(conv + bias).astype(np.float32)).astype(np.float64)
+    act = O.relu(conv + bias)
+    if dt == 'bf16':
+        act = gu.bf16_round(act.astype(np.float32)).astype(np.float64)
     ref = act.reshape(-1, cout) @ w_head.astype(np.float64) + b_head
     ref = ref.reshape(n, h, wd, ncls)
     ran = 0
@@ -239,18 +243,23 @@ def test_conv2d_head_is_conv_then_classifier(cout, cin2, with_res):
         info = (ctypes.c_int * 7)()
         if cfg:
             L.call('fss_conv_config_info', cfg, info)
-        if cfg and not (info[6] == 16 and info[1] >= max(cout, 128)):
+        # float32x3: only tiles with an even number of k steps (128 bytes of K per row)
+        can = info[6] == 16 and info[1] >= max(cout, 128) and (dt == 'bf16' or info[4] == 128)
+        if cfg and not can:
             with pytest.raises(RuntimeError, match='16x16x32'):
-                gu.conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, 2, (2, 2), (h, wd), config=cfg)
+                gu.conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, 2, (2, 2), (h, wd), config=cfg, dt=dt)
             continue
         out = gu.conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, 2, (2, 2), (h, wd), config=cfg,
-                                  y_ld=20 if cfg % 2 else None, residual=res)
-        # a bfloat16 rounding of an activation that sits on a tie may go the other way
-        # (the conv sum is formed in another order than the oracle's): 2^-8 * |w_head| * act
-        _close(out, ref, 2e-2, 'head conv config %d' % cfg)
-        assert np.mean(np.abs(out - ref) > 2e-3) < 0.01, 'config %d' % cfg
+                                  y_ld=20 if cfg % 2 else None, residual=res, dt=dt)
+        if dt == 'bf16':
+            # a bfloat16 rounding of an activation that sits on a tie may go the other way
+            # (the conv sum is formed in another order than the oracle's): 2^-8 * |w_head| * act
+            _close(out, ref, 2e-2, 'head conv config %d' % cfg)
+            assert np.mean(np.abs(out - ref) > 2e-3) < 0.01, 'config %d' % cfg
+        else:
+            _close(out, ref, 2e-4, 'float32x3 head conv config %d' % cfg)
         ran += 1
-    assert ran >= 3
+    assert ran >= (3 if dt == 'bf16' else 1)
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
@@ -278,8 +287,9 @@ def test_dilated_conv_of_a_zoom_at_the_source_resolution(shape, dt):
             _close(out[sl], ref[sl], 2e-5, 'border')
 
 
+@pytest.mark.parametrize('dt', ['bf16', 'f32x3'])
 @pytest.mark.parametrize('n,zh,zw,cout', [(2, 6, 9, 128), (3, 4, 4, 128), (3, 9, 40, 256), (2, 5, 70, 128)])
-def test_head_conv_interpolates_its_residual_from_the_source_resolution(n, zh, zw, cout):
+def test_head_conv_interpolates_its_residual_from_the_source_resolution(n, zh, zw, cout, dt):
     """fss_conv2d_dual_head_nhwc with zoom_residual = {y, ytb, ylr, ycn}: the epilogue adds the
     corrected x2 zoom of y (border rows / columns from the three substitute tensors) exactly
     as fss_zoom2_conv_commute would have stored it; checked against float64.  The shapes cover
@@ -290,11 +300,12 @@ def test_head_conv_interpolates_its_residual_from_the_source_resolution(n, zh, z
     rng = np.random.default_rng(41)
     cin, ncls = 64, 19
     h, wd = 2 * zh - 1, 2 * zw - 1
-    r16 = lambda *shape: gu.bf16_round(rng.normal(0, 1, shape).astype(np.float32))
-    x, w = r16(n, h, wd, cin), gu.bf16_round(rng.normal(0, 0.1, (1, 1, cin, cout)).astype(np.float32))
+    rnd = gu.bf16_round if dt == 'bf16' else (lambda v: v)
+    r16 = lambda *shape: rnd(rng.normal(0, 1, shape).astype(np.float32))
+    x, w = r16(n, h, wd, cin), rnd(rng.normal(0, 0.1, (1, 1, cin, cout)).astype(np.float32))
     y, ytb, ylr, ycn = r16(n, zh, zw, cout), r16(2 * n, 1, zw, cout), r16(2 * n, zh, 1, cout), r16(4 * n, 1, 1, cout)
     bias = rng.normal(0, 1, cout).astype(np.float32)
-    w_head = gu.bf16_round(rng.normal(0, 0.1, (cout, ncls)).astype(np.float32))
+    w_head = rnd(rng.normal(0, 0.1, (cout, ncls)).astype(np.float32))
     b_head = rng.normal(0, 1, ncls).astype(np.float32)
     # the corrected zoom in float64
     z = np.zeros((n, h, wd, cout))
@@ -316,12 +327,17 @@ def test_head_conv_interpolates_its_residual_from_the_source_resolution(n, zh, z
                         srcs.append(ycn[k * n:(k + 1) * n, 0, 0])
             z[:, p, q] = np.mean(np.asarray(srcs, np.float64), axis=0)
     conv = O.conv2d(x, w, 1, 1, 'SAME', np.float64) + bias + z
-    act = gu.bf16_round(O.relu(conv).astype(np.float32)).astype(np.float64)
+    act = O.relu(conv)
+    if dt == 'bf16':
+        act = gu.bf16_round(act.astype(np.float32)).astype(np.float64)
     ref = (act.reshape(-1, cout) @ w_head.astype(np.float64) + b_head).reshape(n, h, wd, ncls)
     out = gu.conv2d_dual_head(x, w, None, None, bias, w_head, b_head, 1, (0, 0), (h, wd),
-                              zoom_residual=(y, ytb, ylr, ycn))
-    _close(out, ref, 2e-2, 'head conv with zoomed residual')
-    assert np.mean(np.abs(out - ref) > 5e-3) < 0.01
+                              zoom_residual=(y, ytb, ylr, ycn), dt=dt)
+    if dt == 'bf16':
+        _close(out, ref, 2e-2, 'head conv with zoomed residual')
+        assert np.mean(np.abs(out - ref) > 5e-3) < 0.01
+    else:
+        _close(out, ref, 2e-4, 'float32x3 head conv with zoomed residual')
 
 
 def test_entry_points_reject_bad_arguments():
