@@ -111,7 +111,7 @@ class Step(object):
 # that points into an activation buffer is read)
 _OUT_ARGS = {
     'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,), 'fss_conv2d_splitk_nhwc': (5, 7),
-    'fss_conv2d_dual_nhwc': (7,),
+    'fss_conv2d_dual_nhwc': (7,), 'fss_conv1x1_chain_nhwc': (11, 17),
     'fss_conv2d_dual_head_nhwc': (13,), 'fss_zoom2_border_gather': (1, 2, 3), 'fss_zoom2_conv_commute': (4,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
     'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1, 7), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
@@ -129,7 +129,7 @@ class CompiledGraph(object):
 
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
-                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True,
+                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True, fuse_chain=True,
                  fuse_head=True, collapse_zooms=True, commute_zoom=None, fuse_zoom_residual=None,
                  ksplit=False):
         if not torch.cuda.is_available():
@@ -167,6 +167,7 @@ class CompiledGraph(object):
         self.fuse_pyramid_pool = fuse_pyramid_pool
         self.fuse_stem2 = fuse_stem2
         self.fuse_dual = fuse_dual
+        self.fuse_chain = fuse_chain and os.environ.get('FSS_FUSE_CHAIN', '1') != '0'
         self.fuse_head = fuse_head
         self.collapse_zooms = collapse_zooms
         self.commute_zoom = commute_zoom
@@ -508,6 +509,57 @@ class CompiledGraph(object):
             return None
         return A
 
+    def _chain_partner(self, result, k, cout, dt):
+        """The 1x1 convolution (batch norm, no biases, stride 1, 32 or 64 filters) among the
+        consumers of `result` that can run in the same launch as the 1x1 convolution producing
+        `result` (fss_conv1x1_chain_nhwc: the end of one bottleneck unit and the first layer of
+        the next, where both are bound by the bytes of `result`)."""
+        if (not self.fuse_chain or dt != 'bf16' or k not in (32, 64, 128) or cout not in (128, 256)
+                or result.is_output):
+            return None
+        for c in result.consumers:
+            if c.kind != 'conv2d' or c.inputs[0] is not result or c in self.fused or c in self.dual:
+                continue
+            a = c.attrs
+            if ((a['kh'], a['kw'], a['stride'], a['rate']) != (1, 1, 1, 1) or a['biases'] is not None
+                    or c.shape[3] not in (32, 64) or c.shape[:3] != result.shape[:3]):
+                continue
+            if self._dual_partner(c) is not None or self._only_consumer(c, 'add') is not None:
+                continue
+            return c
+        return None
+
+    def _emit_chain(self, nxt, nodes, x, x2, Wm, bias, res, act, name):
+        """Emits conv1x1([x | x2], Wm) + bias + res -> act (the value of `nodes`) and the 1x1
+        convolution `nxt` of that value as one launch."""
+        n, ho, wo, cout = nodes[-1].shape
+        cout2 = nxt.shape[3]
+        cin, cin2 = x.shape[3], (x2.shape[3] if x2 is not None else 0)
+        k = cin + cin2
+        wdev = torch.from_numpy(f32_to_bf16_bits(np.ascontiguousarray(Wm, np.float32)).view(np.int16)).to(self.device)
+        s2, b2 = self._fold_bn(nxt.attrs, cout2)
+        W2 = (self.weights[nxt.attrs['weights']].astype(np.float64) * s2).reshape(cout, cout2).T
+        w2dev = torch.from_numpy(f32_to_bf16_bits(np.ascontiguousarray(W2, np.float32)).view(np.int16)).to(self.device)
+        self.keepalive.extend([wdev, w2dev])
+        bdev, b2dev = self._dev_f32(bias), self._dev_f32(b2)
+        self.param_bytes += (cout * k + cout2 * cout) * 2
+        out = Val(self._alloc(nodes[-1].shape, 'bf16'), nodes[-1].shape, 'bf16')
+        out2 = Val(self._alloc(nxt.shape, 'bf16'), nxt.shape, 'bf16')
+        for node in nodes:
+            self.vals[node] = out
+        self.vals[nxt] = out2
+        self.fused.add(nxt)
+        m = n * ho * wo
+        self._emit('chain', name + '+' + '/'.join(nxt.attrs['weights'].split('/')[-4:-1:2]),
+                   'fss_conv1x1_chain_nhwc',
+                   (x.ptr, cin, x.ld, x2.ptr if x2 is not None else None, cin2, x2.ld if x2 is not None else 0,
+                    wdev.data_ptr(), bdev.data_ptr(), res.ptr if res is not None else None,
+                    res.ld if res is not None else 0, _lib.ACT_CODES[act], out.ptr, out.ld, cout,
+                    w2dev.data_ptr(), b2dev.data_ptr(), _lib.ACT_CODES[nxt.attrs['activation']], out2.ptr,
+                    out2.ld, cout2, m, _CODE['bf16'], self.sh),
+                   flops=2 * m * cout * (k + cout2),
+                   nbytes=(m * (k + cout * (2 if res is not None else 1) + cout2) + cout * (k + cout2)) * 2)
+
     def _head_partner(self, result, cout, dt):
         """The 1x1 classifier (a convolution with biases, no normalisation or activation, at
         most 20 classes) that is the only consumer of `result`, when it can run in the
@@ -726,6 +778,10 @@ class CompiledGraph(object):
         bdev = self._dev_f32(bA + bB)
         self.param_bytes += cout * k * _ESZ[x.dt]
         name = b['weights'].rsplit('/', 1)[0] + '+' + A.attrs['weights'].rsplit('/', 2)[-2]
+        if (kh, kw, b['rate'], b['pad_top'], b['pad_left']) == (1, 1, 1, 0, 0) and (h, w) == (ho, wo):
+            nxt = self._chain_partner(result, k, cout, x.dt)
+            if nxt is not None:
+                return self._emit_chain(nxt, (A, B, add, result), x, x2, Wp[:cout, :k], bA + bB, None, act, name)
         head = self._head_partner(result, cout, x.dt)
         if head is not None:
             d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
@@ -797,6 +853,14 @@ class CompiledGraph(object):
         self.keepalive.append(wdev)
         bdev = self._dev_f32(bias)
         self.param_bytes += cout * kh * kw * cin * _ESZ[in_dt]
+        if ((kh, kw, a['stride'], a['rate'], a['pad_top'], a['pad_left']) == (1, 1, 1, 1, 0, 0) and pc == cin
+                and a['biases'] is None and out_dt == in_dt and (h, w) == (ho, wo)
+                and (res is None or (res.dense and res.phys_c == cout))):
+            nxt = self._chain_partner(result, cin, cout, in_dt)
+            if nxt is not None:
+                nodes = (ln,) if result is ln else ((ln, add, result) if result is not add else (ln, add))
+                return self._emit_chain(nxt, nodes, x, None, Wp[:cout, :cin], bias, res, act,
+                                        a['weights'].rsplit('/', 1)[0])
         head = None
         if res is None and a['biases'] is None and pc == cin and cin % 64 == 0 and a['stride'] == 1:
             head = self._head_partner(result, cout, in_dt)

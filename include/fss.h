@@ -176,6 +176,24 @@ int fss_conv2d_dual_head_nhwc(const fss_conv_desc* desc, const void* x, const vo
                               const void* w_head, const float* bias_head, int cout_head,
                               float* y_head, int y_head_ld, void* stream);
 
+/* Two 1x1 convolutions in a row, the first with a residual, as one streaming launch (bfloat16):
+ *   y  = act1(conv1x1([x | x2], w) + bias + residual)       [pixels][cout1], stored
+ *   y2 = act2(conv1x1(y as stored, w2) + bias2)             [pixels][cout2], stored
+ * Replaces the last convolution of a bottleneck unit (with its projection shortcut as the
+ * second input x2, or its identity shortcut as `residual`), the add + relu, and the first
+ * convolution of the next unit (third_party/dilated_resnet_v1.py:50-113) where the filters are
+ * small: cin + cin2 in {32, 64, 128} (each a multiple of 32), cout1 in {128, 256}, cout2 in
+ * {32, 64}.  The cout1-channel tensor is written once and not read back by the second layer.
+ * w: bf16 [cout1][cin + cin2] (batch norm folded in, the channels of x first), w2: bf16
+ * [cout2][cout1]; bias, bias2: float or NULL; residual: bf16 [pixels][cout1] or NULL; *_ld:
+ * pixel strides in elements (multiples of 8).  Equals fss_conv2d_dual_nhwc followed by
+ * fss_conv2d_nhwc up to float summation order. */
+int fss_conv1x1_chain_nhwc(const void* x, int cin, int x_ld, const void* x2, int cin2, int x2_ld,
+                           const void* w, const float* bias, const void* residual, int res_ld,
+                           int act1, void* y, int y_ld, int cout1, const void* w2,
+                           const float* bias2, int act2, void* y2, int y2_ld, int cout2,
+                           long long pixels, int dtype, void* stream);
+
 /* Pieces of  conv3x3_dilation2(zoom_x2(x)) = zoom_x2(conv3x3(x))  (align_corners zoom to
  * (2h-1, 2w-1), zero padding, both sides linear in x), which holds everywhere except on
  * output rows / columns 1 and 2h-3 / 2w-3: there one of the source results that the zoom

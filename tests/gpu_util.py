@@ -175,6 +175,36 @@ def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), ou
     return out[..., :ncls]
 
 
+def conv1x1_chain(x, x2, w, bias, residual, act1, w2, bias2, act2, y_ld=None, y2_ld=None):
+    """act1(conv1x1([x | x2], w) + bias + residual) and act2(conv1x1(of that, as stored, w2) + bias2)
+    through fss_conv1x1_chain_nhwc (bfloat16).  x, x2, residual: [n,h,w,c]; w: [cin (+cin2), cout1];
+    w2: [cout1, cout2].  Returns the two outputs as float32."""
+    n, h, wd, cin = x.shape
+    cin2 = x2.shape[3] if x2 is not None else 0
+    cout1, cout2 = w.shape[1], w2.shape[1]
+    wdev = torch.from_numpy(f32_to_bf16_bits(np.ascontiguousarray(w.T)).view(np.int16)).cuda()
+    w2dev = torch.from_numpy(f32_to_bf16_bits(np.ascontiguousarray(w2.T)).view(np.int16)).cuda()
+    xd = to_dev(x, 'bf16')
+    x2d = to_dev(x2, 'bf16') if cin2 else None
+    rd = to_dev(residual, 'bf16') if residual is not None else None
+    bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda() if bias is not None else None
+    b2d = torch.from_numpy(np.asarray(bias2, np.float32)).cuda() if bias2 is not None else None
+    ld1, ld2 = y_ld or cout1, y2_ld or cout2
+    y = torch.full((n, h, wd, ld1), -77.0, dtype=torch.bfloat16, device='cuda')
+    y2 = torch.full((n, h, wd, ld2), -77.0, dtype=torch.bfloat16, device='cuda')
+    torch.cuda.synchronize()
+    _lib.call('fss_conv1x1_chain_nhwc', xd.data_ptr(), cin, cin, x2d.data_ptr() if cin2 else None, cin2, cin2,
+              wdev.data_ptr(), bd.data_ptr() if bd is not None else None,
+              rd.data_ptr() if rd is not None else None, cout1 if rd is not None else 0,
+              _lib.ACT_CODES[act1], y.data_ptr(), ld1, cout1, w2dev.data_ptr(),
+              b2d.data_ptr() if b2d is not None else None, _lib.ACT_CODES[act2], y2.data_ptr(), ld2, cout2,
+              n * h * wd, _lib.BF16, None)
+    _lib.call('fss_device_sync')
+    o1, o2 = to_host(y), to_host(y2)
+    assert np.all(o1[..., cout1:] == -77.0) and np.all(o2[..., cout2:] == -77.0), 'wrote outside its channels'
+    return o1[..., :cout1], o2[..., :cout2]
+
+
 def zoomed_dilated_conv(x, w, dt='f32'):
     """conv3x3 with dilation 2 (SAME) of the align_corners x2 zoom of x, computed at the source
     resolution: fss_zoom2_border_gather, four fss_conv2d_nhwc launches (x and the three crop

@@ -262,6 +262,50 @@ def test_conv2d_head_is_conv_then_classifier(cout, cin2, with_res, dt):
     assert ran >= (3 if dt == 'bf16' else 1)
 
 
+@pytest.mark.parametrize('cin,cin2,cout1,cout2,with_res,pixels', [
+    (64, 0, 256, 64, True, (2, 19, 31)),       # ICNet-1.0 block1: conv3 + identity shortcut -> conv1
+    (64, 64, 256, 64, False, (1, 9, 17)),      # ... conv3 + projection shortcut -> conv1
+    (32, 0, 128, 32, True, (3, 7, 5)),         # the half-width model; 105 pixels: a partial wave
+    (32, 32, 128, 32, False, (1, 1, 1)),       # one pixel
+    (128, 0, 256, 32, False, (2, 40, 67)),     # several passes per block
+])
+def test_conv1x1_chain_is_two_convolutions(cin, cin2, cout1, cout2, with_res, pixels):
+    """fss_conv1x1_chain_nhwc against the oracle: y = relu(conv1x1([x | x2]) + bias + residual)
+    in float64, rounded to bfloat16 as it is stored, then y2 = relu6(conv1x1(y) + bias2); the
+    first output must also equal the plain two-input convolution bit for bit up to summation
+    order, and the padding channels of wider output rows stay untouched."""
+    gu = _gu()
+    rng = np.random.default_rng(51)
+    n, h, wd = pixels
+    r16 = lambda *shape: gu.bf16_round(rng.normal(0, 1, shape).astype(np.float32))
+    x = r16(n, h, wd, cin)
+    x2 = r16(n, h, wd, cin2) if cin2 else None
+    w = gu.bf16_round(rng.normal(0, 0.1, (cin + cin2, cout1)).astype(np.float32))
+    w2 = gu.bf16_round(rng.normal(0, 0.1, (cout1, cout2)).astype(np.float32))
+    bias, bias2 = rng.normal(0, 1, cout1).astype(np.float32), rng.normal(0, 1, cout2).astype(np.float32)
+    res = r16(n, h, wd, cout1) if with_res else None
+    xin = x if x2 is None else np.concatenate([x, x2], axis=3)
+    pre = xin.reshape(-1, cin + cin2).astype(np.float64) @ w.astype(np.float64) + bias
+    if with_res:
+        pre = pre + res.reshape(-1, cout1)
+    ref1 = O.relu(pre)
+    y, y2 = gu.conv1x1_chain(x, x2, w, bias, res, 'relu', w2, bias2, 'relu6', y_ld=cout1 + 8, y2_ld=cout2 + 16)
+    _close(y.reshape(-1, cout1), ref1, 1.0 / 128, 'chain: first output')
+    # the second layer reads the first output as stored
+    ref2 = np.clip(y.reshape(-1, cout1).astype(np.float64) @ w2.astype(np.float64) + bias2, 0, 6)
+    _close(y2.reshape(-1, cout2), ref2, 1.0 / 128, 'chain: second output')
+    # and equals the unfused kernels on the same inputs
+    if cin % 64 == 0 and cin2 % 64 == 0:
+        w4 = w[:cin].reshape(1, 1, cin, cout1)
+        if cin2:
+            plain = gu.conv2d_dual(x, w4, x2, w[cin:].reshape(1, 1, cin2, cout1), bias, 1, 1, (0, 0), (h, wd),
+                                   'relu', 'bf16')
+        else:
+            plain = gu.conv2d(x, w4, bias=bias, residual=res, out_hw=(h, wd), act='relu', dt='bf16')
+        assert np.mean(plain != y) < 0.01, 'first output differs from the plain convolution on too many values'
+        _close(y, plain, 1.0 / 128, 'chain vs plain convolution')
+
+
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])
 @pytest.mark.parametrize('shape', [(2, 4, 4, 8, 24), (1, 5, 9, 16, 40), (2, 33, 17, 64, 64)])
 def test_dilated_conv_of_a_zoom_at_the_source_resolution(shape, dt):
