@@ -590,69 +590,142 @@ conv_igemm_kernel(const ConvArgs a) {
           // neighbourhood (a source counted twice or four times where a step is 0), so that the
           // loads are independent and in flight together.  Where the whole wave has even rows,
           // u2 = u0 and u3 = u1: half of (u0 + u1) is the same number, from two loads.
-          Raw8 u[4];
-          const unsigned zbase = (zo[i] & ~15u) + (unsigned)(32 * s) * ESZ;
-          const unsigned zdr = (zo[i] & 1u) ? zrow : 0u, zdc = (zo[i] & 2u) ? zpix : 0u;
-          const bool two = zeven[i] && !zborder[i];
-          if (two) {
-            u[0] = raw8(zyb + zbase);
-            u[1] = raw8(zyb + (zbase + zdc));
-            u[2] = u[3] = u[0];                  // not used
-          } else if (!zborder[i]) {
+          if constexpr (!SPLIT) {
+            uint4 u[4];
+            const unsigned zbase = (zo[i] & ~15u) + (unsigned)(64 * s);
+            const unsigned zdr = (zo[i] & 1u) ? zrow : 0u, zdc = (zo[i] & 2u) ? zpix : 0u;
+            const bool two = zeven[i] && !zborder[i];
+            if (two) {
+              u[0] = *reinterpret_cast<const uint4*>(zyb + zbase);
+              u[1] = *reinterpret_cast<const uint4*>(zyb + (zbase + zdc));
+              u[2] = u[3] = make_uint4(0u, 0u, 0u, 0u);
+            } else if (!zborder[i]) {
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
-              u[nb] = raw8(zyb + (zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u)));
+              for (int nb = 0; nb < 4; ++nb)
+                u[nb] = *reinterpret_cast<const uint4*>(zyb + (zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u)));
+            } else {
+              // next to the frame border a source row / column is replaced by its corrected copy
+              const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
+              const int f = m / HoWo, rem = m - f * HoWo;
+              const int p = rem / a.Wo, q = rem - p * a.Wo;
+              const unsigned lane_c = (unsigned)(c0 + 8 * lg) * (unsigned)sizeof(T);
+#pragma unroll
+              for (int nb = 0; nb < 4; ++nb) {
+                const int zi = (p >> 1) + ((nb >> 1) & p), zj = (q >> 1) + (nb & q & 1);
+                const int rf = (p == 1 && zi == 1) ? 1 : (p == a.Ho - 2 && zi == a.zH - 2) ? 2 : 0;
+                const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
+                const char* base = zyb;
+                unsigned off = zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u);
+                if (rf != 0 && cf == 0) {
+                  base = reinterpret_cast<const char*>(a.zytb);
+                  off = (unsigned)(((rf - 1) * a.N + f) * a.zW + zj) * zpix + lane_c;
+                }
+                if (rf == 0 && cf != 0) {
+                  base = reinterpret_cast<const char*>(a.zylr);
+                  off = (unsigned)(((cf - 1) * a.N + f) * a.zH + zi) * zpix + lane_c;
+                }
+                if (rf != 0 && cf != 0) {
+                  base = reinterpret_cast<const char*>(a.zycn);
+                  off = (unsigned)(((rf - 1) * 2 + (cf - 1)) * a.N + f) * zpix + lane_c;
+                }
+                u[nb] = *reinterpret_cast<const uint4*>(base + off);
+              }
+            }
+            auto lo = [](unsigned v) { return __uint_as_float(v << 16); };
+            auto hi = [](unsigned v) { return __uint_as_float(v & 0xffff0000u); };
+            float r0[4], r1[4];
+            r0[0] = lo(u[0].x) + lo(u[1].x); r0[1] = hi(u[0].x) + hi(u[1].x);
+            r0[2] = lo(u[0].y) + lo(u[1].y); r0[3] = hi(u[0].y) + hi(u[1].y);
+            r1[0] = lo(u[0].z) + lo(u[1].z); r1[1] = hi(u[0].z) + hi(u[1].z);
+            r1[2] = lo(u[0].w) + lo(u[1].w); r1[3] = hi(u[0].w) + hi(u[1].w);
+            if (two) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.5f; d1[e] += r1[e] * 0.5f; }
+            } else {
+              r0[0] += lo(u[2].x) + lo(u[3].x); r0[1] += hi(u[2].x) + hi(u[3].x);
+              r0[2] += lo(u[2].y) + lo(u[3].y); r0[3] += hi(u[2].y) + hi(u[3].y);
+              r1[0] += lo(u[2].z) + lo(u[3].z); r1[1] += hi(u[2].z) + hi(u[3].z);
+              r1[2] += lo(u[2].w) + lo(u[3].w); r1[3] += hi(u[2].w) + hi(u[3].w);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.25f; d1[e] += r1[e] * 0.25f; }
+            }
           } else {
-            // next to the frame border a source row / column is replaced by its corrected copy
-            const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
-            const int f = m / HoWo, rem = m - f * HoWo;
-            const int p = rem / a.Wo, q = rem - p * a.Wo;
-            const unsigned lane_c = (unsigned)(c0 + 8 * lg) * ESZ;
+            Raw8 u[4];
+            const unsigned zbase = (zo[i] & ~15u) + (unsigned)(32 * s) * ESZ;
+            const unsigned zdr = (zo[i] & 1u) ? zrow : 0u, zdc = (zo[i] & 2u) ? zpix : 0u;
+            const bool two = zeven[i] && !zborder[i];
+            if (two) {
+              u[0] = raw8(zyb + zbase);
+              u[1] = raw8(zyb + (zbase + zdc));
+              u[2] = u[3] = u[0];                  // not used
+            } else if (!zborder[i]) {
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-              const int zi = (p >> 1) + ((nb >> 1) & p), zj = (q >> 1) + (nb & q & 1);
-              const int rf = (p == 1 && zi == 1) ? 1 : (p == a.Ho - 2 && zi == a.zH - 2) ? 2 : 0;
-              const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
-              const char* base = zyb;
-              unsigned off = zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u);
-              if (rf != 0 && cf == 0) {
-                base = reinterpret_cast<const char*>(a.zytb);
-                off = (unsigned)(((rf - 1) * a.N + f) * a.zW + zj) * zpix + lane_c;
+              for (int nb = 0; nb < 4; ++nb)
+                u[nb] = raw8(zyb + (zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u)));
+            } else {
+              // next to the frame border a source row / column is replaced by its corrected copy
+              const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
+              const int f = m / HoWo, rem = m - f * HoWo;
+              const int p = rem / a.Wo, q = rem - p * a.Wo;
+              const unsigned lane_c = (unsigned)(c0 + 8 * lg) * ESZ;
+#pragma unroll
+              for (int nb = 0; nb < 4; ++nb) {
+                const int zi = (p >> 1) + ((nb >> 1) & p), zj = (q >> 1) + (nb & q & 1);
+                const int rf = (p == 1 && zi == 1) ? 1 : (p == a.Ho - 2 && zi == a.zH - 2) ? 2 : 0;
+                const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
+                const char* base = zyb;
+                unsigned off = zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u);
+                if (rf != 0 && cf == 0) {
+                  base = reinterpret_cast<const char*>(a.zytb);
+                  off = (unsigned)(((rf - 1) * a.N + f) * a.zW + zj) * zpix + lane_c;
+                }
+                if (rf == 0 && cf != 0) {
+                  base = reinterpret_cast<const char*>(a.zylr);
+                  off = (unsigned)(((cf - 1) * a.N + f) * a.zH + zi) * zpix + lane_c;
+                }
+                if (rf != 0 && cf != 0) {
+                  base = reinterpret_cast<const char*>(a.zycn);
+                  off = (unsigned)(((rf - 1) * 2 + (cf - 1)) * a.N + f) * zpix + lane_c;
+                }
+                u[nb] = raw8(base + off);
               }
-              if (rf == 0 && cf != 0) {
-                base = reinterpret_cast<const char*>(a.zylr);
-                off = (unsigned)(((cf - 1) * a.N + f) * a.zH + zi) * zpix + lane_c;
-              }
-              if (rf != 0 && cf != 0) {
-                base = reinterpret_cast<const char*>(a.zycn);
-                off = (unsigned)(((rf - 1) * 2 + (cf - 1)) * a.N + f) * zpix + lane_c;
-              }
-              u[nb] = raw8(base + off);
+            }
+            float f0[8], f1[8], r8[8];
+            floats8(u[0], f0);
+            floats8(u[1], f1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r8[e] = f0[e] + f1[e];
+            if (two) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { d0[e] += r8[e] * 0.5f; d1[e] += r8[4 + e] * 0.5f; }
+            } else {
+              floats8(u[2], f0);
+              floats8(u[3], f1);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) r8[e] += f0[e] + f1[e];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { d0[e] += r8[e] * 0.25f; d1[e] += r8[4 + e] * 0.25f; }
             }
           }
-          float f0[8], f1[8], r8[8];
-          floats8(u[0], f0);
-          floats8(u[1], f1);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) r8[e] = f0[e] + f1[e];
-          if (two) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { d0[e] += r8[e] * 0.5f; d1[e] += r8[4 + e] * 0.5f; }
-          } else {
-            floats8(u[2], f0);
-            floats8(u[3], f1);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) r8[e] += f0[e] + f1[e];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { d0[e] += r8[e] * 0.25f; d1[e] += r8[4 + e] * 0.25f; }
-          }
         } else if (a.res != nullptr) {
-          const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
-          if (m < a.M) {
-            float f0[8];
-            floats8(raw8(reinterpret_cast<const char*>(a.res) + ((size_t)m * a.res_ld + c0 + 8 * lg) * ESZ), f0);
+          if constexpr (!SPLIT) {
+            const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
+            if (m < a.M) {
+              const uint4 rv = *reinterpret_cast<const uint4*>(
+                  reinterpret_cast<const T*>(a.res) + (size_t)m * a.res_ld + c0 + 8 * lg);
+              d0[0] += __uint_as_float(rv.x << 16); d0[1] += __uint_as_float(rv.x & 0xffff0000u);
+              d0[2] += __uint_as_float(rv.y << 16); d0[3] += __uint_as_float(rv.y & 0xffff0000u);
+              d1[0] += __uint_as_float(rv.z << 16); d1[1] += __uint_as_float(rv.z & 0xffff0000u);
+              d1[2] += __uint_as_float(rv.w << 16); d1[3] += __uint_as_float(rv.w & 0xffff0000u);
+            }
+          } else {
+            const int m = tile_m * BM + wm * WTM + i * 16 + lrow;
+            if (m < a.M) {
+              float f0[8];
+              floats8(raw8(reinterpret_cast<const char*>(a.res) + ((size_t)m * a.res_ld + c0 + 8 * lg) * ESZ), f0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { d0[e] += f0[e]; d1[e] += f0[4 + e]; }
+              for (int e = 0; e < 4; ++e) { d0[e] += f0[e]; d1[e] += f0[4 + e]; }
+            }
           }
         }
         auto cl = [&](float v) { return fminf(fmaxf(v, act_lo), act_hi); };
