@@ -207,7 +207,14 @@ __global__ void pyramid_add_kernel(const T* __restrict__ x, T* __restrict__ y, P
     Chunk<T> acc[kPyrPix];
 #pragma unroll
     for (int k = 0; k < kPyrPix; ++k)
-      if (ow0 + k < W) acc[k].load(x + row_base + (size_t)k * C + (size_t)ch * E);
+      if (ow0 + k < W) {
+        if (x != nullptr) {
+          acc[k].load(x + row_base + (size_t)k * C + (size_t)ch * E);
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) acc[k].v[e] = 0.f;
+        }
+      }
     for (int l = 0; l < a.levels; ++l) {
       const int bh = a.bh[l], bw = a.bw[l];
       int y0, y1;
@@ -1216,7 +1223,7 @@ int fss_resize_bilinear_nhwc(const void* x, void* y, int n, int h, int wd, int c
 int fss_pyramid_add_nhwc(const void* x, const void* const* p, const int* bh, const int* bw,
                          int levels, void* y, int n, int h, int wd, int c, int dtype,
                          void* stream) {
-  FSS_REQUIRE(x && y && p && bh && bw, "null argument");
+  FSS_REQUIRE(y && p && bh && bw, "null argument");
   FSS_DTYPE_OK(dtype);
   FSS_CHUNK_OK(c, dtype);
   FSS_ALIGNED(x); FSS_ALIGNED(y);

@@ -129,7 +129,7 @@ class CompiledGraph(object):
 
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
-                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True, fuse_chain=True,
+                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True, fuse_chain=True, commute_pyramid=None,
                  fuse_head=True, collapse_zooms=True, commute_zoom=None, fuse_zoom_residual=None,
                  ksplit=False):
         if not torch.cuda.is_available():
@@ -168,6 +168,7 @@ class CompiledGraph(object):
         self.fuse_stem2 = fuse_stem2
         self.fuse_dual = fuse_dual
         self.fuse_chain = fuse_chain and os.environ.get('FSS_FUSE_CHAIN', '1') != '0'
+        self.commute_pyramid = commute_pyramid
         self.fuse_head = fuse_head
         self.collapse_zooms = collapse_zooms
         self.commute_zoom = commute_zoom
@@ -802,11 +803,100 @@ class CompiledGraph(object):
                     out.ptr, self.sh),
                    flops=2 * n * ho * wo * cout * k, nbytes=nbytes, keep=d)
 
+    def _pyramid_source(self, ln):
+        """(base node, level values) when conv `ln` is the 1x1 convolution behind the deferred sum
+        x + sum_f resize(pool_f(x)) of a fast pyramid pooling module
+        (architectures/icnet_architecture.py:194-210) that nothing else reads."""
+        # None: only from FSS_COMMUTE_MIN_BATCH frames per launch on (the extra small launches
+        # cost more than the saved pass over the tensor at small batches)
+        if self.commute_pyramid is False or os.environ.get('FSS_COMMUTE_PYRAMID', '1') == '0':
+            return None
+        if self.commute_pyramid is None and ln.shape[0] < int(os.environ.get('FSS_COMMUTE_MIN_BATCH', '8')):
+            return None
+        a, src = ln.attrs, ln.inputs[0]
+        d = self.lazy.get(src)
+        if not d or d[0] != 'pyramid' or src.is_output or len(src.consumers) != 1:
+            return None
+        if ((a['kh'], a['kw'], a['stride'], a['rate'], a['pad_top'], a['pad_left']) != (1, 1, 1, 1, 0, 0)
+                or a['biases'] is not None or self._only_consumer(ln, 'add') is not None
+                or ln in self.dual or self._dual_partner(ln) is not None):
+            return None
+        if ln.shape[3] % _EPC[self.dt] or d[1].shape[3] % 64:
+            return None
+        return d[1], d[2]
+
+    def _l_conv_pyramid(self, ln, base, levels):
+        """conv1x1(x + sum_f resize(p_f)) as conv1x1(x) + sum_f resize(conv1x1(p_f)): a 1x1
+        convolution acts on every pixel alone and is linear, the align_corners resize is a
+        weighted mean of pixels, so the two commute.  The small maps are convolved first (a few
+        hundred pixels each), their resized sum is formed at the OUTPUT channel count and enters
+        the convolution of x as its residual; the sum at the input channel count (a read and a
+        write of the whole tensor) is never formed."""
+        a = ln.attrs
+        x = self._val(base)
+        if not (x.dense and x.phys_c == base.shape[3]):
+            raise NotImplementedError('pyramid base must be dense')
+        self.lazy.pop(ln.inputs[0])
+        dt = x.dt
+        n, h, w, cin = x.shape
+        cout = ln.shape[3]
+        scale, bias = self._fold_bn(a, cout)
+        Wt = self.weights[a['weights']].astype(np.float64) * scale
+        k_pad, cout_pad = _lib.conv_pack_dims(cin, 1, 1, cout, _CODE[dt])
+        Wp = np.zeros((cout_pad, k_pad), np.float32)
+        Wp[:cout, :cin] = Wt.reshape(cin, cout).T
+        if dt == 'bf16':
+            wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+        elif self.split:
+            wdev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
+        else:
+            wdev = torch.from_numpy(Wp).to(self.device)
+        self.keepalive.append(wdev)
+        bdev = self._dev_f32(bias)
+        self.param_bytes += cout * cin * _ESZ[dt]
+        name = a['weights'].rsplit('/', 1)[0]
+        esz = _ESZ[dt]
+        small = []
+        for i, t in enumerate(levels):
+            nn, bh, bw, _ = t.shape
+            y = Val(self._alloc((nn, bh, bw, cout), dt), (nn, bh, bw, cout), dt)
+            d = _lib.ConvDesc(n=nn, h=bh, w=bw, cin=cin, cout=cout, kh=1, kw=1, stride=1, dilation=1,
+                              pad_top=0, pad_left=0, ho=bh, wo=bw, act=_lib.ACT_CODES[None],
+                              in_dtype=self._in_code(dt), out_dtype=_CODE[dt], y_ld=y.ld, res_ld=0,
+                              k_pad=k_pad, cout_pad=cout_pad)
+            self._emit('conv', '%s@level%d' % (name, i), 'fss_conv2d_nhwc',
+                       (ctypes.byref(d), t.ptr, wdev.data_ptr(), None, None, y.ptr, self.sh),
+                       flops=2 * nn * bh * bw * cout * cin,
+                       nbytes=(nn * bh * bw * (cin + cout) + cout * cin) * esz, keep=d, graph_flops=0)
+            small.append(y)
+        r = Val(self._alloc((n, h, w, cout), dt), (n, h, w, cout), dt)
+        L = len(small)
+        ptrs = (ctypes.c_void_p * L)(*[t.ptr for t in small])
+        bhs = (ctypes.c_int * L)(*[t.shape[1] for t in small])
+        bws = (ctypes.c_int * L)(*[t.shape[2] for t in small])
+        self._emit('pyramid', name + '/pyramid_sum', 'fss_pyramid_add_nhwc',
+                   (None, ptrs, bhs, bws, L, r.ptr, n, h, w, cout, _CODE[dt], self.sh),
+                   nbytes=n * h * w * cout * esz, keep=(ptrs, bhs, bws))
+        self.temps.extend(small + [r])
+        out = Val(self._alloc(ln.shape, dt), ln.shape, dt)
+        self.vals[ln] = out
+        d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=1, kw=1, stride=1, dilation=1,
+                          pad_top=0, pad_left=0, ho=h, wo=w, act=_lib.ACT_CODES[a['activation']],
+                          in_dtype=self._in_code(dt), out_dtype=_CODE[dt], y_ld=out.ld, res_ld=r.ld,
+                          k_pad=k_pad, cout_pad=cout_pad)
+        self._emit('conv', name, 'fss_conv2d_nhwc',
+                   (ctypes.byref(d), x.ptr, wdev.data_ptr(), bdev.data_ptr(), r.ptr, out.ptr, self.sh),
+                   flops=2 * n * h * w * cout * cin,
+                   nbytes=(n * h * w * (cin + 2 * cout) + cout * cin) * esz, keep=d)
+
     def _l_conv(self, ln):
         a = ln.attrs
         stem = self._stem_source(ln)
         if stem is not None:
             return self._l_stem_conv(ln, *stem)
+        pyr = self._pyramid_source(ln)
+        if pyr is not None:
+            return self._l_conv_pyramid(ln, *pyr)
         if ln in self.dual:
             return self._l_conv_dual(ln, self.dual[ln])
         partner = self._dual_partner(ln)

@@ -280,7 +280,10 @@ int fss_resize_bilinear_nhwc(const void* x, void* y, int n, int h, int wd, int c
 
 /* y = x + sum_i resize_bilinear_align_corners(p_i) for up to 8 pooled maps,
  * added in index order.  Replaces the avg_pool -> resize -> tf.add loop of
- * architectures/icnet_architecture.py:194-205.  p[i]: [n,bh[i],bw[i],c]. */
+ * architectures/icnet_architecture.py:194-205.  p[i]: [n,bh[i],bw[i],c].
+ * x = NULL: the sum of the resized maps alone (used when the 1x1 convolution that follows the
+ * loop, architectures/icnet_architecture.py:206-210, is applied to x and to the small maps
+ * separately, both operations being linear, and this sum is that convolution's residual). */
 int fss_pyramid_add_nhwc(const void* x, const void* const* p, const int* bh,
                          const int* bw, int levels, void* y, int n, int h, int wd,
                          int c, int dtype, void* stream);

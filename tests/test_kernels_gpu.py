@@ -777,6 +777,10 @@ def test_pyramid_add(dt):
     _call('fss_pyramid_add_nhwc', xd.data_ptr(), ptrs, bh, bw, 4, y.data_ptr(), n, h, wd, c, code,
           None)
     _close(gu.to_host(y), ref, 2e-6 if dt == 'f32' else 1.0 / 128, 'pyramid')
+    # without a base tensor: the sum of the resized maps alone
+    y.fill_(-5.0)
+    _call('fss_pyramid_add_nhwc', None, ptrs, bh, bw, 4, y.data_ptr(), n, h, wd, c, code, None)
+    _close(gu.to_host(y), ref - x, 2e-6 if dt == 'f32' else 1.0 / 128, 'pyramid sum without a base')
 
 
 @pytest.mark.parametrize('dt', ['f32', 'bf16'])

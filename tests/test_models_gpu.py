@@ -76,7 +76,7 @@ def test_forward_parity(case, dtype):
     ref = oracle_logits(arch, ext, fs, pf, img, pad_shape, weights)
     # commute_zoom=True: the plan large batches get (fusion convs in front of their zoom); the
     # small-batch plan is compared with it in test_layer_fusions_agree_with_the_unfused_plan
-    cg = plan.CompiledGraph(g, outs, weights, dtype=dtype, commute_zoom=True)
+    cg = plan.CompiledGraph(g, outs, weights, dtype=dtype, commute_zoom=True, commute_pyramid=True)
     logits, labels, colors = cg.run(img)
     assert logits.shape == ref.shape
     scale = float(np.abs(ref).max())
@@ -365,7 +365,7 @@ def test_layer_fusions_agree_with_the_unfused_plan(dtype):
     arch, ext, fs, pf, in_shape, pad_shape = CASES[0]
     g, cfg, outs, weights = build(arch, ext, fs, pf, in_shape, pad_shape)
     img = np.random.default_rng(5).integers(0, 256, in_shape).astype(np.uint8)
-    ref_plan = plan.CompiledGraph(g, outs, weights, dtype=dtype, streams=1, commute_zoom=True)
+    ref_plan = plan.CompiledGraph(g, outs, weights, dtype=dtype, streams=1, commute_zoom=True, commute_pyramid=True)
     kinds = [s.kind for s in ref_plan.steps]
     fnames = list(ref_plan.step_fname)
     assert 'fss_conv2d_dual_nhwc' in fnames, 'ICNet must use the two-input convolution'
@@ -375,10 +375,21 @@ def test_layer_fusions_agree_with_the_unfused_plan(dtype):
     ref = ref_plan.run(img)[0]
     scale = float(np.abs(ref).max())
     assert 'fss_zoom2_conv_commute' in fnames, 'ICNet must run the fusion\'s dilated conv before the zoom'
+    assert any(s.name.endswith('/pyramid_sum') for s in ref_plan.steps), \
+        'ICNet must apply the pyramid module\'s 1x1 convolution to the pooled maps'
+    if dtype == 'bfloat16':
+        assert 'fss_conv1x1_chain_nhwc' in fnames, 'ResNet block1 in bfloat16 must chain conv3 and the next conv1'
     for kw in (dict(fuse_stem2=False), dict(fuse_dual=False), dict(fuse_head=False), dict(commute_zoom=False),
-               dict(fuse_stem2=False, fuse_dual=False, fuse_head=False, commute_zoom=False)):
+               dict(commute_pyramid=False), dict(fuse_chain=False),
+               dict(fuse_stem2=False, fuse_dual=False, fuse_head=False, commute_zoom=False,
+                    commute_pyramid=False, fuse_chain=False)):
         kw.setdefault('commute_zoom', True)
+        kw.setdefault('commute_pyramid', True)
         cg = plan.CompiledGraph(g, outs, weights, dtype=dtype, streams=1, **kw)
+        if not kw.get('commute_pyramid', True):
+            assert not any(s.name.endswith('/pyramid_sum') for s in cg.steps)
+        if not kw.get('fuse_chain', True):
+            assert 'fss_conv1x1_chain_nhwc' not in cg.step_fname
         if not kw.get('fuse_head', True):
             assert 'fss_conv2d_dual_head_nhwc' not in cg.step_fname
         if not kw.get('commute_zoom', True):
