@@ -458,6 +458,27 @@ def test_entry_points_reject_bad_arguments():
                                      29, 29, None)
     assert 'multiple of 16 bytes' in rejected('fss_dwconv2d_nhwc', x.data_ptr(), b.data_ptr(), b.data_ptr(),
                                               y.data_ptr(), 1, 8, 8, 12, 3, 3, 1, 1, 1, 1, 8, 8, 0, L.BF16, None)
+    # the two-layer 1x1 launch: x [64 px, 64], w [256][64], y [64 px, 256], w2 [64][256], y2 [64 px, 64]
+    y1 = torch.zeros((64, 256), dtype=torch.bfloat16, device='cuda')
+
+    def chain(**kw):
+        a = dict(x=x.data_ptr(), cin=64, x_ld=64, x2=None, cin2=0, x2_ld=0, w=w.data_ptr(), bias=None, res=None,
+                 res_ld=0, act1=1, y=y1.data_ptr(), y_ld=256, cout1=256, w2=w.data_ptr(), bias2=None, act2=1,
+                 y2=y.data_ptr(), y2_ld=64, cout2=64, pixels=64, dtype=L.BF16)
+        a.update(kw)
+        return rejected('fss_conv1x1_chain_nhwc', *a.values(), None)
+    assert 'null' in chain(w2=None)
+    assert 'bfloat16' in chain(dtype=L.F32)
+    assert 'cin' in chain(cin=48, x_ld=48)
+    assert 'cin2 = 0 without' in chain(cin2=64)
+    assert '32, 64 or 128' in chain(cin=64, x2=x.data_ptr(), cin2=32, x2_ld=32)
+    assert 'cout1' in chain(cout1=192)
+    assert 'cout2' in chain(cout2=128, y2_ld=128)
+    assert 'pixel strides' in chain(y_ld=250)
+    assert 'pixel strides' in chain(res=y1.data_ptr(), res_ld=128)
+    assert 'unaligned' in chain(y=y1.data_ptr() + 2)
+    assert 'bad act' in chain(act2=7)
+    assert 'bad shape' in chain(pixels=0)
     L.call('fss_device_sync')
 
 
