@@ -650,18 +650,16 @@ conv_igemm_kernel(const ConvArgs a) {
               for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.25f; d1[e] += r1[e] * 0.25f; }
             }
           } else {
-            Raw8 u[4];
+            // float sources: the addresses of the (up to) four sources first, then 4 channels
+            // (one 16-byte load per source) at a time, so that at most four loaded vectors are live
             const unsigned zbase = (zo[i] & ~15u) + (unsigned)(32 * s) * ESZ;
             const unsigned zdr = (zo[i] & 1u) ? zrow : 0u, zdc = (zo[i] & 2u) ? zpix : 0u;
             const bool two = zeven[i] && !zborder[i];
-            if (two) {
-              u[0] = raw8(zyb + zbase);
-              u[1] = raw8(zyb + (zbase + zdc));
-              u[2] = u[3] = u[0];                  // not used
-            } else if (!zborder[i]) {
+            const char* src[4];
+            if (!zborder[i]) {
 #pragma unroll
               for (int nb = 0; nb < 4; ++nb)
-                u[nb] = raw8(zyb + (zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u)));
+                src[nb] = zyb + (zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u));
             } else {
               // next to the frame border a source row / column is replaced by its corrected copy
               const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
@@ -687,24 +685,23 @@ conv_igemm_kernel(const ConvArgs a) {
                   base = reinterpret_cast<const char*>(a.zycn);
                   off = (unsigned)(((rf - 1) * 2 + (cf - 1)) * a.N + f) * zpix + lane_c;
                 }
-                u[nb] = raw8(base + off);
+                src[nb] = base + off;
               }
             }
-            float f0[8], f1[8], r8[8];
-            floats8(u[0], f0);
-            floats8(u[1], f1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r8[e] = f0[e] + f1[e];
-            if (two) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { d0[e] += r8[e] * 0.5f; d1[e] += r8[4 + e] * 0.5f; }
-            } else {
-              floats8(u[2], f0);
-              floats8(u[3], f1);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) r8[e] += f0[e] + f1[e];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { d0[e] += r8[e] * 0.25f; d1[e] += r8[4 + e] * 0.25f; }
+            for (int hh = 0; hh < 2; ++hh) {
+              f32x4& d = hh == 0 ? d0 : d1;
+              const float4 t0 = *reinterpret_cast<const float4*>(src[0] + 16 * hh);
+              const float4 t1 = *reinterpret_cast<const float4*>(src[1] + 16 * hh);
+              if (two) {
+                d[0] += (t0.x + t1.x) * 0.5f; d[1] += (t0.y + t1.y) * 0.5f;
+                d[2] += (t0.z + t1.z) * 0.5f; d[3] += (t0.w + t1.w) * 0.5f;
+              } else {
+                const float4 t2 = *reinterpret_cast<const float4*>(src[2] + 16 * hh);
+                const float4 t3 = *reinterpret_cast<const float4*>(src[3] + 16 * hh);
+                d[0] += ((t0.x + t1.x) + (t2.x + t3.x)) * 0.25f; d[1] += ((t0.y + t1.y) + (t2.y + t3.y)) * 0.25f;
+                d[2] += ((t0.z + t1.z) + (t2.z + t3.z)) * 0.25f; d[3] += ((t0.w + t1.w) + (t2.w + t3.w)) * 0.25f;
+              }
             }
           }
         } else if (a.res != nullptr) {
