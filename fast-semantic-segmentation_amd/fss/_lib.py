@@ -70,6 +70,7 @@ PROTOTYPES = {
     'fss_conv1x1_chain_nhwc': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                        c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                        c_int, c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_void_p]),
+    'fss_conv3x3_c64_nhwc': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
     'fss_zoom2_border_gather': (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     'fss_zoom2_conv_commute': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     'fss_stem_pack_dims': (c_int, [c_int, c_int, c_int, c_int, c_int_p, c_int_p]),

@@ -111,7 +111,7 @@ class Step(object):
 # that points into an activation buffer is read)
 _OUT_ARGS = {
     'fss_preprocess_u8': (1,), 'fss_stem_conv_u8': (3,), 'fss_stem2_conv_u8': (5,), 'fss_conv2d_nhwc': (5,), 'fss_conv2d_splitk_nhwc': (5, 7),
-    'fss_conv2d_dual_nhwc': (7,), 'fss_conv1x1_chain_nhwc': (11, 17),
+    'fss_conv2d_dual_nhwc': (7,), 'fss_conv1x1_chain_nhwc': (11, 17), 'fss_conv3x3_c64_nhwc': (4,),
     'fss_conv2d_dual_head_nhwc': (13,), 'fss_zoom2_border_gather': (1, 2, 3), 'fss_zoom2_conv_commute': (4,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
     'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1, 7), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
@@ -129,7 +129,7 @@ class CompiledGraph(object):
 
     def __init__(self, graph, outputs, weights, dtype='bfloat16', device=None,
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
-                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True, fuse_chain=True, commute_pyramid=None,
+                 fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True, fuse_chain=True, commute_pyramid=None, resident_3x3=True,
                  fuse_head=True, collapse_zooms=True, commute_zoom=None, fuse_zoom_residual=None,
                  ksplit=False):
         if not torch.cuda.is_available():
@@ -169,6 +169,7 @@ class CompiledGraph(object):
         self.fuse_dual = fuse_dual
         self.fuse_chain = fuse_chain and os.environ.get('FSS_FUSE_CHAIN', '1') != '0'
         self.commute_pyramid = commute_pyramid
+        self.resident_3x3 = resident_3x3 and os.environ.get('FSS_RESIDENT_3X3', '1') != '0'
         self.fuse_head = fuse_head
         self.collapse_zooms = collapse_zooms
         self.commute_zoom = commute_zoom
@@ -951,6 +952,22 @@ class CompiledGraph(object):
                 nodes = (ln,) if result is ln else ((ln, add, result) if result is not add else (ln, add))
                 return self._emit_chain(nxt, nodes, x, None, Wp[:cout, :cin], bias, res, act,
                                         a['weights'].rsplit('/', 1)[0])
+        if (self.resident_3x3 and (kh, kw) == (3, 3) and pc == cin == 64 and cout in (64, 128) and in_dt == 'bf16'
+                and out_dt == in_dt and res is None and a['biases'] is None and h * w * x.ld < 2 ** 31
+                and (cout == 128 or a['stride'] == 2)):
+            # 64 input channels: the filter stays in LDS, the activations go straight to the MFMAs
+            # (measured faster than the implicit GEMM for 128 filters and for stride 2: `Conv_2`
+            # 0.92 -> 0.80 ms, block1/unit_3/conv2 0.212 -> 0.202 ms per 128 frames; at stride 1 with
+            # 64 filters 0.57 -> 0.59 ms, not taken)
+            out = Val(self._alloc(ln.shape, out_dt), ln.shape, out_dt)
+            self.vals[result] = out
+            self._emit('conv3x3', a['weights'].rsplit('/', 1)[0], 'fss_conv3x3_c64_nhwc',
+                       (x.ptr, x.ld, wdev.data_ptr(), bdev.data_ptr(), out.ptr, out.ld, n, h, w, ho, wo, cout,
+                        a['stride'], a['rate'], a['pad_top'], a['pad_left'], _lib.ACT_CODES[act], _CODE[in_dt],
+                        self.sh),
+                       flops=2 * n * ho * wo * cout * 9 * cin,
+                       nbytes=(n * h * w * cin + n * ho * wo * cout + cout * 9 * cin) * 2)
+            return
         head = None
         if res is None and a['biases'] is None and pc == cin and cin % 64 == 0 and a['stride'] == 1:
             head = self._head_partner(result, cout, in_dt)

@@ -194,6 +194,19 @@ int fss_conv1x1_chain_nhwc(const void* x, int cin, int x_ld, const void* x2, int
                            const float* bias2, int act2, void* y2, int y2_ld, int cout2,
                            long long pixels, int dtype, void* stream);
 
+/* 3x3 convolution of a 64-channel bfloat16 tensor with the whole filter resident in LDS:
+ *   y = act(conv3x3(x, w) + bias),  cout 64 or 128, any stride (<= 4), dilation, padding.
+ * Same result as fss_conv2d_nhwc up to float summation order; for the layers whose K axis
+ * (576) is too short for the implicit GEMM to amortise its staging: conv2 of the first ResNet
+ * block's units (third_party/dilated_resnet_v1.py:95-97) and `Conv_2` of the full-resolution
+ * branch (architectures/icnet_architecture.py:220-222).  w: bf16 [cout][576], k = (r*3 + s)*64
+ * + c, batch norm folded in (the first cout rows of fss_conv2d_nhwc's packed matrix, whose row
+ * length for this layer is 576 too); bias: float [cout] or NULL; x_ld / y_ld: pixel strides in
+ * elements (multiples of 8). */
+int fss_conv3x3_c64_nhwc(const void* x, int x_ld, const void* w, const float* bias, void* y,
+                         int y_ld, int n, int h, int wd, int ho, int wo, int cout, int stride,
+                         int dilation, int pad_top, int pad_left, int act, int dtype, void* stream);
+
 /* Pieces of  conv3x3_dilation2(zoom_x2(x)) = zoom_x2(conv3x3(x))  (align_corners zoom to
  * (2h-1, 2w-1), zero padding, both sides linear in x), which holds everywhere except on
  * output rows / columns 1 and 2h-3 / 2w-3: there one of the source results that the zoom

@@ -205,6 +205,28 @@ def conv1x1_chain(x, x2, w, bias, residual, act1, w2, bias2, act2, y_ld=None, y2
     return o1[..., :cout1], o2[..., :cout2]
 
 
+def conv3x3_c64(x, w, bias, stride, rate, pads, out_hw, act, y_ld=None):
+    """act(conv3x3(x, w) + bias) through fss_conv3x3_c64_nhwc (bfloat16, 64 input channels, filter
+    resident in LDS).  x: [n,h,w,64]; w: [3,3,64,cout].  Returns float32 [n,ho,wo,cout]."""
+    n, h, wd, cin = x.shape
+    cout = w.shape[3]
+    ho, wo = out_hw
+    wdev = torch.from_numpy(f32_to_bf16_bits(np.ascontiguousarray(w.transpose(3, 0, 1, 2).reshape(cout, -1)))
+                            .view(np.int16)).cuda()
+    xd = to_dev(x, 'bf16')
+    bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda() if bias is not None else None
+    ld = y_ld or cout
+    y = torch.full((n, ho, wo, ld), -77.0, dtype=torch.bfloat16, device='cuda')
+    torch.cuda.synchronize()
+    _lib.call('fss_conv3x3_c64_nhwc', xd.data_ptr(), cin, wdev.data_ptr(), bd.data_ptr() if bd is not None else None,
+              y.data_ptr(), ld, n, h, wd, ho, wo, cout, stride, rate, pads[0], pads[1], _lib.ACT_CODES[act],
+              _lib.BF16, None)
+    _lib.call('fss_device_sync')
+    out = to_host(y)
+    assert np.all(out[..., cout:] == -77.0), 'wrote outside its channels'
+    return out[..., :cout]
+
+
 def zoomed_dilated_conv(x, w, dt='f32'):
     """conv3x3 with dilation 2 (SAME) of the align_corners x2 zoom of x, computed at the source
     resolution: fss_zoom2_border_gather, four fss_conv2d_nhwc launches (x and the three crop

@@ -262,6 +262,33 @@ def test_conv2d_head_is_conv_then_classifier(cout, cin2, with_res, dt):
     assert ran >= (3 if dt == 'bf16' else 1)
 
 
+@pytest.mark.parametrize('n,h,wd,cout,stride,rate,mode', [
+    (2, 19, 31, 64, 1, 1, 'SAME'),        # block1 conv2; pixels do not fill the last pass
+    (1, 33, 17, 128, 2, 1, 'SAME'),       # `Conv_2`: stride 2 on odd sizes
+    (1, 16, 24, 64, 2, 1, 'SAME'),        # stride 2 on even sizes (asymmetric padding)
+    (2, 9, 13, 64, 2, 1, 'FIXED'),        # conv2d_same: explicit symmetric padding, then VALID
+    (1, 21, 20, 128, 1, 2, 'SAME'),       # dilation 2
+    (3, 40, 67, 64, 1, 1, 'SAME'),        # several passes per block, rows that wrap inside a pixel group
+    (1, 3, 3, 64, 1, 1, 'SAME'),          # every tap of most pixels on the padding
+])
+def test_conv3x3_c64_matches_oracle(n, h, wd, cout, stride, rate, mode):
+    """fss_conv3x3_c64_nhwc (filter resident in LDS) against the oracle's convolution in float64 and
+    against fss_conv2d_nhwc on the same inputs (same products, another summation order)."""
+    gu = _gu()
+    rng = np.random.default_rng(61)
+    x = gu.bf16_round(rng.normal(0, 1, (n, h, wd, 64)).astype(np.float32))
+    w = gu.bf16_round(rng.normal(0, 0.05, (3, 3, 64, cout)).astype(np.float32))
+    bias = rng.normal(0, 1, cout).astype(np.float32)
+    ref = O.relu(_conv_ref(x, w, stride, rate, mode) + bias)
+    pads, (ho, wo) = _conv_pads(h, wd, 3, stride, rate, mode)
+    assert ref.shape[1:3] == (ho, wo)
+    out = gu.conv3x3_c64(x, w, bias, stride, rate, pads, (ho, wo), 'relu', y_ld=cout + 8)
+    _close(out, ref, 1.0 / 128, 'resident 3x3')
+    plain = gu.conv2d(x, w, bias=bias, stride=stride, rate=rate, pads=pads, out_hw=(ho, wo), act='relu', dt='bf16')
+    assert np.mean(plain != out) < 0.01
+    _close(out, plain, 1.0 / 128, 'resident 3x3 vs implicit GEMM')
+
+
 @pytest.mark.parametrize('cin,cin2,cout1,cout2,with_res,pixels', [
     (64, 0, 256, 64, True, (2, 19, 31)),       # ICNet-1.0 block1: conv3 + identity shortcut -> conv1
     (64, 64, 256, 64, False, (1, 9, 17)),      # ... conv3 + projection shortcut -> conv1
