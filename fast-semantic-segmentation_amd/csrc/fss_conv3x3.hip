@@ -20,6 +20,7 @@
 // loads run two taps ahead of the MFMAs through a ring of registers, across pass boundaries,
 // and the loop body has no branch around a load or a store (see fss_chain.hip for why).
 #include <algorithm>
+#include <type_traits>
 
 #include "fss_common.h"
 
@@ -189,11 +190,207 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_kernel(const Conv3A
   }
 }
 
+// Stride 1, dilation 1: the three horizontal taps of 16 consecutive pixels of one image row are
+// 18 consecutive input pixels, so tap (kr, 0) of the group's lanes plus the two pixels after
+// them are all a filter row needs; taps (kr, 1) and (kr, 2) are the same registers shifted by
+// one and two lanes (DPP row shifts: the 16 lanes of a DPP row are exactly one pixel group of
+// one channel group).  Two loads per filter row, channel half and group (the second with only
+// lanes 14 and 15 active) instead of three: the load path, which bounds this kernel, carries
+// 0.4x the bytes.  A group whose pixels wrap around the end of an image row takes the plain
+// three loads.  The ring is two filter rows deep; two passes (six rows) per trip keep its
+// indices compile-time constants.
 template <int C1P>
+__global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64s1_kernel(const Conv3Args a) {
+  constexpr int C1 = 32 * C1P, NT = kC3Waves * 64;
+  constexpr int OFF_B = 2 * C1P * kC3Steps * 1024;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wl = smem;
+  float* bl = reinterpret_cast<float*>(smem + OFF_B);
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int r = lane & 15, g = lane >> 4;
+  for (int idx = tid; idx < C1 * 72; idx += NT) {
+    const int row = idx / 72, c = idx - row * 72;
+    *reinterpret_cast<uint4*>(wl + c3_lds_offset(row >> 4, c >> 2, row & 15, c & 3)) =
+        *reinterpret_cast<const uint4*>(a.w + (size_t)c3_channel(row >> 4, row & 15) * 576 + c * 8);
+  }
+  for (int idx = tid; idx < C1; idx += NT) bl[idx] = a.bias != nullptr ? a.bias[idx] : 0.f;
+  __syncthreads();
+
+  const float lo = a.act == FSS_ACT_NONE ? -INFINITY : 0.f, hi = a.act == FSS_ACT_RELU6 ? 6.f : INFINITY;
+  const char* wfrag = wl + c3_lds_offset(0, 0, r, g);
+  const long long passes = (a.M + kC3Pixels - 1) / kC3Pixels;
+  const int HoWo = a.Ho * a.Wo;
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_c3_zero);
+  constexpr int NTILE = 2 * C1P;
+
+  struct Coord { const bf16_t* frame; int off00; unsigned ok; long long m; bool wrap; };
+  auto coord = [&](long long pass, int grp) {
+    pass = pass < passes ? pass : passes - 1;
+    const long long m_real = pass * kC3Pixels + wave * 32 + grp * 16 + r;
+    const long long m = m_real < a.M ? m_real : a.M - 1;
+    const int n = (int)(m / HoWo), rem = (int)(m - (long long)n * HoWo);
+    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+    const int ih0 = oh - a.pad_t, iw0 = ow - a.pad_l;
+    Coord c;
+    c.frame = a.x + ((size_t)n * a.H * a.W) * a.x_ld + 8 * g;
+    c.off00 = (ih0 * a.W + iw0) * a.x_ld;
+    unsigned rows = 0, cols = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      rows |= ((unsigned)(ih0 + k) < (unsigned)a.H ? 7u : 0u) << (3 * k);
+      cols |= ((unsigned)(iw0 + k) < (unsigned)a.W ? 0x49u : 0u) << k;
+    }
+    c.ok = rows & cols;
+    c.m = m;
+    // the 16 pixels of the group are 16 consecutive columns of one image row (and none of them
+    // stands in for a pixel past the end): lane 0's column decides, for every lane alike
+    const int ow_first = __builtin_amdgcn_readfirstlane(ow);     // lane 0 of the wave = pixel 0 of the group
+    const long long m_first = (long long)pass * kC3Pixels + wave * 32 + grp * 16;
+    c.wrap = ow_first + 15 >= a.Wo || m_first + 15 >= a.M;
+    return c;
+  };
+  int dtap[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) dtap[t] = ((t / 3) * a.W + (t % 3)) * a.x_ld;
+  // raw registers of one filter row of one group: shared form {tap 0 of every lane, tap 2 of
+  // lanes 14 and 15}, plain form {tap 0, tap 1, tap 2}; two channel halves each
+  struct Row { uint4 v[3][2]; };
+  auto load_one = [&](const Coord& c, int t, uint4 (&dst)[2]) {
+    const bool ok = (c.ok >> t) & 1u;
+    const bf16_t* p = ok ? c.frame + (c.off00 + dtap[t]) : zero;
+    dst[0] = *reinterpret_cast<const uint4*>(p);
+    dst[1] = *reinterpret_cast<const uint4*>(p + (ok ? 32 : 0));
+  };
+  auto load_row = [&](const Coord& c, int kr, Row& row) {
+    load_one(c, 3 * kr, row.v[0]);
+    if (c.wrap) {                       // wave-uniform
+      load_one(c, 3 * kr + 1, row.v[1]);
+      load_one(c, 3 * kr + 2, row.v[2]);
+    } else if (r >= 14) {
+      load_one(c, 3 * kr + 2, row.v[2]);
+    }
+  };
+  auto shl = [](unsigned old, unsigned src, auto ctrl) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, decltype(ctrl)::value, 0xf, 0xf, false);
+  };
+  // the three taps of a filter row from its raw registers
+  auto taps_of = [&](const Row& row, bool wrap, uint4 (&tap)[3][2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      tap[0][h] = row.v[0][h];
+      if (wrap) {
+        tap[1][h] = row.v[1][h];
+        tap[2][h] = row.v[2][h];
+      } else {
+        const unsigned l0[4] = {row.v[0][h].x, row.v[0][h].y, row.v[0][h].z, row.v[0][h].w};
+        const unsigned xx[4] = {row.v[2][h].x, row.v[2][h].y, row.v[2][h].z, row.v[2][h].w};
+        unsigned t1[4], t2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // lane 15 of tap 1: lane 14's extra pixel; lanes 14, 15 of tap 2: their own extra pixels
+          const unsigned xs = shl(0u, xx[e], std::integral_constant<int, 0x111>{});     // row_shr:1
+          t1[e] = shl(xs, l0[e], std::integral_constant<int, 0x101>{});                // row_shl:1
+          t2[e] = shl(xx[e], l0[e], std::integral_constant<int, 0x102>{});             // row_shl:2
+        }
+        tap[1][h] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+        tap[2][h] = make_uint4(t2[0], t2[1], t2[2], t2[3]);
+      }
+    }
+  };
+
+  const long long step = gridDim.x;
+  long long pass = blockIdx.x;
+  if (pass >= passes) return;
+  Row ring[2][2];                       // [slot][group]
+  Coord c0 = coord(pass, 0), c1 = coord(pass, 1);
+  load_row(c0, 0, ring[0][0]);
+  load_row(c1, 0, ring[0][1]);
+  f32x4 acc[NTILE][2];
+  // one filter row of the current pass from ring slot `slot`, after which the slot is refilled
+  // with row `kr + 2` (of the next pass for kr >= 1)
+  auto do_row = [&](auto slot_c, int kr, const Coord& cc0, const Coord& cc1, const Coord& nn0, const Coord& nn1) {
+    constexpr int slot = decltype(slot_c)::value;
+    // the row after this one goes into the other slot first, so that it is in flight under
+    // this row's MFMAs
+    if (kr + 1 < 3) {
+      load_row(cc0, kr + 1, ring[slot ^ 1][0]);
+      load_row(cc1, kr + 1, ring[slot ^ 1][1]);
+    } else {
+      load_row(nn0, 0, ring[slot ^ 1][0]);
+      load_row(nn1, 0, ring[slot ^ 1][1]);
+    }
+    uint4 tap[2][3][2];
+    taps_of(ring[slot][0], cc0.wrap, tap[0]);
+    taps_of(ring[slot][1], cc1.wrap, tap[1]);
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < NTILE; ++j) {
+          const uint4 wa = *reinterpret_cast<const uint4*>(wfrag + (j * kC3Steps + 2 * (3 * kr + ks) + h) * 1024);
+#pragma unroll
+          for (int grp = 0; grp < 2; ++grp)
+            acc[j][grp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, tap[grp][ks][h]), acc[j][grp], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+  auto begin_pass = [&]() {
+#pragma unroll
+    for (int j = 0; j < NTILE; ++j) {
+      const float4 b = *reinterpret_cast<const float4*>(bl + 32 * (j >> 1) + 8 * g + 4 * (j & 1));
+      acc[j][0] = acc[j][1] = f32x4{b.x, b.y, b.z, b.w};
+    }
+  };
+  auto end_pass = [&](const Coord& cc0, const Coord& cc1) {
+#pragma unroll
+    for (int grp = 0; grp < 2; ++grp) {
+      bf16_t* py = a.y + (size_t)(grp == 0 ? cc0.m : cc1.m) * a.y_ld + 8 * g;
+#pragma unroll
+      for (int u = 0; u < C1P; ++u) {
+        float v[8] = {acc[2 * u][grp][0], acc[2 * u][grp][1], acc[2 * u][grp][2], acc[2 * u][grp][3],
+                      acc[2 * u + 1][grp][0], acc[2 * u + 1][grp][1], acc[2 * u + 1][grp][2], acc[2 * u + 1][grp][3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
+        store16_nt(py + 32 * u, pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                   pack_bf16x2(v[6], v[7]));
+      }
+    }
+  };
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
+  while (true) {
+    // pass A: rows 0, 1, 2 from slots 0, 1, 0
+    Coord n0 = coord(pass + step, 0), n1 = coord(pass + step, 1);
+    begin_pass();
+    do_row(S0{}, 0, c0, c1, n0, n1);
+    do_row(S1{}, 1, c0, c1, n0, n1);
+    do_row(S0{}, 2, c0, c1, n0, n1);
+    end_pass(c0, c1);
+    pass += step;
+    if (pass >= passes) break;
+    // pass B: rows 0, 1, 2 from slots 1, 0, 1
+    c0 = n0; c1 = n1;
+    n0 = coord(pass + step, 0); n1 = coord(pass + step, 1);
+    begin_pass();
+    do_row(S1{}, 0, c0, c1, n0, n1);
+    do_row(S0{}, 1, c0, c1, n0, n1);
+    do_row(S1{}, 2, c0, c1, n0, n1);
+    end_pass(c0, c1);
+    pass += step;
+    if (pass >= passes) break;
+    c0 = n0; c1 = n1;
+  }
+}
+
+template <int C1P, bool SHARED_TAPS>
 static int launch_conv3(const Conv3Args& a, hipStream_t stream) {
   constexpr size_t smem = (size_t)2 * C1P * kC3Steps * 1024 + 32 * C1P * 4;
   static_assert(smem <= 160 * 1024, "filter too large for LDS");
-  auto kern = conv3x3_c64_kernel<C1P>;
+  auto kern = SHARED_TAPS ? conv3x3_c64s1_kernel<C1P> : conv3x3_c64_kernel<C1P>;
   static bool attr_set = false;   // per instantiation
   if (smem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -257,5 +454,8 @@ extern "C" int fss_conv3x3_c64_nhwc(const void* x, int x_ld, const void* w, cons
   a.N = n; a.H = h; a.W = wd; a.Ho = ho; a.Wo = wo; a.stride = stride; a.dil = dilation;
   a.pad_t = pad_top; a.pad_l = pad_left; a.x_ld = x_ld; a.y_ld = y_ld; a.act = act;
   hipStream_t s = (hipStream_t)stream;
-  return cout == 64 ? launch_conv3<2>(a, s) : launch_conv3<4>(a, s);
+  // stride 1, dilation 1: horizontal taps shared between lanes
+  const bool shared = stride == 1 && dilation == 1 && getenv("FSS_C3_PLAIN") == nullptr;
+  if (shared) return cout == 64 ? launch_conv3<2, true>(a, s) : launch_conv3<4, true>(a, s);
+  return cout == 64 ? launch_conv3<2, false>(a, s) : launch_conv3<4, false>(a, s);
 }

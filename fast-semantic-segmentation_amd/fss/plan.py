@@ -954,11 +954,11 @@ class CompiledGraph(object):
                                         a['weights'].rsplit('/', 1)[0])
         if (self.resident_3x3 and (kh, kw) == (3, 3) and pc == cin == 64 and cout in (64, 128) and in_dt == 'bf16'
                 and out_dt == in_dt and res is None and a['biases'] is None and h * w * x.ld < 2 ** 31
-                and (cout == 128 or a['stride'] == 2)):
+                and (cout == 128 or a['stride'] == 2 or (a['stride'], a['rate']) == (1, 1))):
             # 64 input channels: the filter stays in LDS, the activations go straight to the MFMAs
             # (measured faster than the implicit GEMM for 128 filters and for stride 2: `Conv_2`
-            # 0.92 -> 0.80 ms, block1/unit_3/conv2 0.212 -> 0.202 ms per 128 frames; at stride 1 with
-            # 64 filters 0.57 -> 0.59 ms, not taken)
+            # 0.92 -> 0.80 ms, block1/unit_3/conv2 0.212 -> 0.202 ms per 128 frames; and at stride 1,
+            # dilation 1, where the horizontal taps are shared between lanes)
             out = Val(self._alloc(ln.shape, out_dt), ln.shape, out_dt)
             self.vals[result] = out
             self._emit('conv3x3', a['weights'].rsplit('/', 1)[0], 'fss_conv3x3_c64_nhwc',
