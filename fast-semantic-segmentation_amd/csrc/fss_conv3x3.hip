@@ -199,8 +199,13 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_kernel(const Conv3A
 // 0.4x the bytes.  A group whose pixels wrap around the end of an image row takes the plain
 // three loads.  The ring is two filter rows deep; two passes (six rows) per trip keep its
 // indices compile-time constants.
-template <int C1P>
-__global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64s1_kernel(const Conv3Args a) {
+//
+// Stride 2: tap (kr, 2) of a pixel is tap (kr, 0) of its right neighbour, so tap 0 and tap 1 are
+// loaded by every lane, tap 2 by lane 15 only, and the other lanes take tap 2 from the next
+// lane's tap 0.
+template <int C1P, int STRIDE>
+__global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_shared_kernel(const Conv3Args a) {
+  static_assert(STRIDE == 1 || STRIDE == 2, "lane sharing is worked out for strides 1 and 2");
   constexpr int C1 = 32 * C1P, NT = kC3Waves * 64;
   constexpr int OFF_B = 2 * C1P * kC3Steps * 1024;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,7 +236,7 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64s1_kernel(const Conv
     const long long m = m_real < a.M ? m_real : a.M - 1;
     const int n = (int)(m / HoWo), rem = (int)(m - (long long)n * HoWo);
     const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-    const int ih0 = oh - a.pad_t, iw0 = ow - a.pad_l;
+    const int ih0 = oh * STRIDE - a.pad_t, iw0 = ow * STRIDE - a.pad_l;
     Coord c;
     c.frame = a.x + ((size_t)n * a.H * a.W) * a.x_ld + 8 * g;
     c.off00 = (ih0 * a.W + iw0) * a.x_ld;
@@ -267,8 +272,9 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64s1_kernel(const Conv
     if (c.wrap) {                       // wave-uniform
       load_one(c, 3 * kr + 1, row.v[1]);
       load_one(c, 3 * kr + 2, row.v[2]);
-    } else if (r >= 14) {
-      load_one(c, 3 * kr + 2, row.v[2]);
+    } else {
+      if (STRIDE == 2) load_one(c, 3 * kr + 1, row.v[1]);
+      if (r >= (STRIDE == 1 ? 14 : 15)) load_one(c, 3 * kr + 2, row.v[2]);
     }
   };
   auto shl = [](unsigned old, unsigned src, auto ctrl) {
@@ -286,14 +292,21 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64s1_kernel(const Conv
         const unsigned l0[4] = {row.v[0][h].x, row.v[0][h].y, row.v[0][h].z, row.v[0][h].w};
         const unsigned xx[4] = {row.v[2][h].x, row.v[2][h].y, row.v[2][h].z, row.v[2][h].w};
         unsigned t1[4], t2[4];
+        if constexpr (STRIDE == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          // lane 15 of tap 1: lane 14's extra pixel; lanes 14, 15 of tap 2: their own extra pixels
-          const unsigned xs = shl(0u, xx[e], std::integral_constant<int, 0x111>{});     // row_shr:1
-          t1[e] = shl(xs, l0[e], std::integral_constant<int, 0x101>{});                // row_shl:1
-          t2[e] = shl(xx[e], l0[e], std::integral_constant<int, 0x102>{});             // row_shl:2
+          for (int e = 0; e < 4; ++e) {
+            // lane 15 of tap 1: lane 14's extra pixel; lanes 14, 15 of tap 2: their own extra pixels
+            const unsigned xs = shl(0u, xx[e], std::integral_constant<int, 0x111>{});     // row_shr:1
+            t1[e] = shl(xs, l0[e], std::integral_constant<int, 0x101>{});                // row_shl:1
+            t2[e] = shl(xx[e], l0[e], std::integral_constant<int, 0x102>{});             // row_shl:2
+          }
+          tap[1][h] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
+        } else {
+          // lane 15 of tap 2: its own extra pixel
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t2[e] = shl(xx[e], l0[e], std::integral_constant<int, 0x101>{});
+          tap[1][h] = row.v[1][h];
         }
-        tap[1][h] = make_uint4(t1[0], t1[1], t1[2], t1[3]);
         tap[2][h] = make_uint4(t2[0], t2[1], t2[2], t2[3]);
       }
     }
@@ -386,11 +399,13 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64s1_kernel(const Conv
   }
 }
 
-template <int C1P, bool SHARED_TAPS>
+// SHARED: 0 = every tap loaded, 1 / 2 = taps shared between lanes at that stride
+template <int C1P, int SHARED>
 static int launch_conv3(const Conv3Args& a, hipStream_t stream) {
   constexpr size_t smem = (size_t)2 * C1P * kC3Steps * 1024 + 32 * C1P * 4;
   static_assert(smem <= 160 * 1024, "filter too large for LDS");
-  auto kern = SHARED_TAPS ? conv3x3_c64s1_kernel<C1P> : conv3x3_c64_kernel<C1P>;
+  auto kern = SHARED == 1 ? conv3x3_c64_shared_kernel<C1P, 1>
+              : SHARED == 2 ? conv3x3_c64_shared_kernel<C1P, 2> : conv3x3_c64_kernel<C1P>;
   static bool attr_set = false;   // per instantiation
   if (smem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -455,7 +470,8 @@ extern "C" int fss_conv3x3_c64_nhwc(const void* x, int x_ld, const void* w, cons
   a.pad_t = pad_top; a.pad_l = pad_left; a.x_ld = x_ld; a.y_ld = y_ld; a.act = act;
   hipStream_t s = (hipStream_t)stream;
   // stride 1, dilation 1: horizontal taps shared between lanes
-  const bool shared = stride == 1 && dilation == 1 && getenv("FSS_C3_PLAIN") == nullptr;
-  if (shared) return cout == 64 ? launch_conv3<2, true>(a, s) : launch_conv3<4, true>(a, s);
-  return cout == 64 ? launch_conv3<2, false>(a, s) : launch_conv3<4, false>(a, s);
+  const int shared = dilation == 1 && stride <= 2 && getenv("FSS_C3_PLAIN") == nullptr ? stride : 0;
+  if (shared == 1) return cout == 64 ? launch_conv3<2, 1>(a, s) : launch_conv3<4, 1>(a, s);
+  if (shared == 2) return cout == 64 ? launch_conv3<2, 2>(a, s) : launch_conv3<4, 2>(a, s);
+  return cout == 64 ? launch_conv3<2, 0>(a, s) : launch_conv3<4, 0>(a, s);
 }
