@@ -336,20 +336,36 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_shared_kernel(const
     uint4 tap[2][3][2];
     taps_of(ring[slot][0], cc0.wrap, tap[0]);
     taps_of(ring[slot][1], cc1.wrap, tap[1]);
+    // The six k steps of the row (3 taps x 2 channel halves).  With 64 filters the weight
+    // fragments of step i + 1 are read while the MFMAs of step i run (two register sets); with
+    // 128 filters there are no registers left for that.
+    constexpr bool WPIPE = NTILE <= 4;
+    uint4 wq[2][NTILE];
+    auto read_w = [&](int i, uint4 (&dst)[NTILE]) {
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks)
+      for (int j = 0; j < NTILE; ++j)
+        dst[j] = *reinterpret_cast<const uint4*>(wfrag + (j * kC3Steps + 6 * kr + i) * 1024);
+    };
+    if constexpr (WPIPE) {
+      read_w(0, wq[0]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int j = 0; j < NTILE; ++j) {
-          const uint4 wa = *reinterpret_cast<const uint4*>(wfrag + (j * kC3Steps + 2 * (3 * kr + ks) + h) * 1024);
-#pragma unroll
-          for (int grp = 0; grp < 2; ++grp)
-            acc[j][grp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, tap[grp][ks][h]), acc[j][grp], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 6; ++i) {
+      if constexpr (WPIPE) {
+        if (i + 1 < 6) read_w(i + 1, wq[(i + 1) & 1]);
+      } else {
+        read_w(i, wq[0]);
       }
+#pragma unroll
+      for (int j = 0; j < NTILE; ++j)
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp)
+          acc[j][grp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+              __builtin_bit_cast(bf16x8_t, wq[WPIPE ? (i & 1) : 0][j]),
+              __builtin_bit_cast(bf16x8_t, tap[grp][i >> 1][i & 1]), acc[j][grp], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
   auto begin_pass = [&]() {
 #pragma unroll

@@ -506,6 +506,21 @@ def test_entry_points_reject_bad_arguments():
     assert 'unaligned' in chain(y=y1.data_ptr() + 2)
     assert 'bad act' in chain(act2=7)
     assert 'bad shape' in chain(pixels=0)
+    # the LDS-resident 3x3 convolution of 64 channels
+
+    def c3(**kw):
+        a = dict(x=x.data_ptr(), x_ld=64, w=w.data_ptr(), bias=None, y=y1.data_ptr(), y_ld=64, n=1, h=8, wd=8, ho=8,
+                 wo=8, cout=64, stride=1, dilation=1, pad_top=1, pad_left=1, act=1, dtype=L.BF16)
+        a.update(kw)
+        return rejected('fss_conv3x3_c64_nhwc', *a.values(), None)
+    assert 'null' in c3(w=None)
+    assert 'bfloat16' in c3(dtype=L.F32)
+    assert 'cout' in c3(cout=96, y_ld=96)
+    assert 'stride' in c3(stride=5)
+    assert 'output size' in c3(ho=12)
+    assert 'pixel strides' in c3(x_ld=60)
+    assert 'unaligned' in c3(x=x.data_ptr() + 2)
+    assert 'bad act' in c3(act=9)
     L.call('fss_device_sync')
 
 
