@@ -336,10 +336,10 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_shared_kernel(const
     uint4 tap[2][3][2];
     taps_of(ring[slot][0], cc0.wrap, tap[0]);
     taps_of(ring[slot][1], cc1.wrap, tap[1]);
-    // The six k steps of the row (3 taps x 2 channel halves).  With 64 filters the weight
-    // fragments of step i + 1 are read while the MFMAs of step i run (two register sets); with
-    // 128 filters there are no registers left for that.
-    constexpr bool WPIPE = NTILE <= 4;
+    // The six k steps of the row (3 taps x 2 channel halves).  The weight fragments of step
+    // i + 1 are read while the MFMAs of step i run (two register sets), except with 128 filters
+    // at stride 1, where no registers are left for that.
+    constexpr bool WPIPE = NTILE <= 4 || STRIDE == 2;
     uint4 wq[2][NTILE];
     auto read_w = [&](int i, uint4 (&dst)[NTILE]) {
 #pragma unroll
