@@ -28,9 +28,9 @@ INPUT_SHAPE = (1024, 2048, 3)
 PAD_SHAPE = (1025, 2049)
 # dense peaks (MI355X): bf16 MFMA ~2.5 PFLOP/s, f32 MFMA 157.3 TFLOP/s.  float32x3 issues three
 # bf16 MFMAs per product: its convolution FLOP are priced x3 against the bf16 peak.
-PEAK_TFLOPS = {'bfloat16': 2500.0, 'float32': 157.3, 'float32x3': 2500.0}
-MFMA_PER_PRODUCT = {'bfloat16': 1, 'float32': 1, 'float32x3': 3}
-DTYPE_TAG = {'bfloat16': 'bf16', 'float32': 'f32', 'float32x3': 'f32 (bf16x3 products)'}
+PEAK_TFLOPS = {'bfloat16': 2500.0, 'float32': 157.3, 'float32x3': 2500.0, 'mixed': 2500.0}
+MFMA_PER_PRODUCT = {'bfloat16': 1, 'float32': 1, 'float32x3': 3, 'mixed': 1}
+DTYPE_TAG = {'bfloat16': 'bf16', 'float32': 'f32', 'float32x3': 'f32 (bf16x3 products)', 'mixed': 'f32 (bf16x3 products) + f16'}
 
 
 def measured_conv_traffic(batch, n_conv, dtype):
@@ -182,7 +182,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=128, help='frames per step per GPU')
-    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32', 'float32x3'])
+    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32', 'float32x3', 'mixed'])
     ap.add_argument('--no-conformant', action='store_true',
                     help='skip the float32x3 (all tolerances met) figure and the parity figures')
     ap.add_argument('--no-host-fed', action='store_true')

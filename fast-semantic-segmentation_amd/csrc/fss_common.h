@@ -61,6 +61,53 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f, fss_bf16x2));
 }
 
+// IEEE half precision: the compiler's own type as the storage tag (distinct from bf16_t for the
+// template machinery; two bytes).  Conversions round to nearest even (v_cvt_pk_f16_f32).
+typedef _Float16 f16_t;
+typedef _Float16 fss_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+  fss_f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, fss_f16x2));
+}
+
+// What the kernels need to know about a 16-bit storage type: two floats -> one dword and back,
+// the bit pattern of the pair (1.0, 1.0), one value -> its bits.
+template <typename T> struct Half16;
+template <> struct Half16<bf16_t> {
+  static constexpr unsigned kOnePair = 0x3f803f80u;
+  static __device__ __forceinline__ unsigned pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+  static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ unsigned bits(float v) { return f32_to_bf16(v); }
+  static __device__ __forceinline__ float value(unsigned b) { return __uint_as_float(b << 16); }
+};
+template <> struct Half16<f16_t> {
+  static constexpr unsigned kOnePair = 0x3c003c00u;
+  static __device__ __forceinline__ unsigned pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+  static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(fss_f16x2, w)[0]; }
+  static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(fss_f16x2, w)[1]; }
+  static __device__ __forceinline__ unsigned bits(float v) {
+    return __builtin_bit_cast(unsigned short, (f16_t)v);
+  }
+  static __device__ __forceinline__ float value(unsigned b) {
+    return (float)__builtin_bit_cast(f16_t, (unsigned short)b);
+  }
+};
+
+// One 16x16x32 MFMA step on 8 + 8 values of a 16-bit type held as raw 16-byte vectors.
+typedef float fss_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 fss_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fss_f16x8 __attribute__((ext_vector_type(8)));
+template <typename T>
+__device__ __forceinline__ fss_f32x4 mfma_16x16x32(const uint4& a, const uint4& b, fss_f32x4 acc) {
+  if constexpr (sizeof(T) == 2 && __is_same(T, f16_t))
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(fss_f16x8, a), __builtin_bit_cast(fss_f16x8, b),
+                                                  acc, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fss_bf16x8, a),
+                                                   __builtin_bit_cast(fss_bf16x8, b), acc, 0, 0, 0);
+}
+
 // 16-byte store that does not keep the line in the caches (outputs far larger than L2 that
 // the same kernel never reads back)
 typedef unsigned fss_u32x4 __attribute__((ext_vector_type(4)));
@@ -79,6 +126,14 @@ template <> struct ElemTraits<bf16_t> {
   static constexpr int kPerChunk = 8;
   static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
   static __device__ __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+template <> struct ElemTraits<f16_t> {
+  static constexpr int kPerChunk = 8;
+  static __device__ __forceinline__ float load(const f16_t* p) { return (float)*p; }
+  static __device__ __forceinline__ void store(f16_t* p, float v) {
+    *p = (f16_t)fminf(fmaxf(v, -65504.f), 65504.f);   // saturates instead of overflowing
+  }
 };
 
 // A 16-byte chunk of T viewed as floats.

@@ -1,4 +1,6 @@
-// 3x3 convolution of a 64-channel tensor with the whole filter resident in LDS (gfx950, bf16):
+// 3x3 convolution of a 64-channel tensor with the whole filter resident in LDS (gfx950; bfloat16
+// or half precision: the template parameter H names the 16-bit type, everything but the MFMA
+// instruction and the rounding of the outputs is the same):
 //
 //   y = act(conv3x3(x, W) + bias),  cin = 64, cout = 64 or 128, any stride / dilation / padding
 //
@@ -29,6 +31,7 @@ namespace fss {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
+// (tensor pointers as raw 16-bit words: bfloat16 or half, the kernels' template parameter says which)
 struct Conv3Args {
   const bf16_t* x;
   const bf16_t* w;
@@ -58,7 +61,7 @@ __device__ __forceinline__ int c3_channel(int j, int rho) {
 }
 
 // C1P = cout / 32
-template <int C1P>
+template <typename H, int C1P>
 __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_kernel(const Conv3Args a) {
   constexpr int C1 = 32 * C1P, NT = kC3Waves * 64;
   constexpr int OFF_B = 2 * C1P * kC3Steps * 1024;
@@ -155,8 +158,7 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_kernel(const Conv3A
           const uint4 wa = *reinterpret_cast<const uint4*>(wfrag + (j * kC3Steps + 2 * t + h) * 1024);
 #pragma unroll
           for (int grp = 0; grp < 2; ++grp)
-            acc[j][grp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8_t, wa), __builtin_bit_cast(bf16x8_t, ring[t % 3][grp][h]), acc[j][grp], 0, 0, 0);
+            acc[j][grp] = mfma_16x16x32<H>(wa, ring[t % 3][grp][h], acc[j][grp]);
         }
         // keep the weight reads of later k steps from being hoisted above this point (they
         // would all be live at once)
@@ -179,8 +181,8 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_kernel(const Conv3A
                       acc[2 * u + 1][grp][0], acc[2 * u + 1][grp][1], acc[2 * u + 1][grp][2], acc[2 * u + 1][grp][3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
-        store16_nt(py + 32 * u, pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                   pack_bf16x2(v[6], v[7]));
+        store16_nt(py + 32 * u, Half16<H>::pack2(v[0], v[1]), Half16<H>::pack2(v[2], v[3]),
+                   Half16<H>::pack2(v[4], v[5]), Half16<H>::pack2(v[6], v[7]));
       }
     }
     c0 = n0;
@@ -203,7 +205,7 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_kernel(const Conv3A
 // Stride 2: tap (kr, 2) of a pixel is tap (kr, 0) of its right neighbour, so tap 0 and tap 1 are
 // loaded by every lane, tap 2 by lane 15 only, and the other lanes take tap 2 from the next
 // lane's tap 0.
-template <int C1P, int STRIDE>
+template <typename H, int C1P, int STRIDE>
 __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_shared_kernel(const Conv3Args a) {
   static_assert(STRIDE == 1 || STRIDE == 2, "lane sharing is worked out for strides 1 and 2");
   constexpr int C1 = 32 * C1P, NT = kC3Waves * 64;
@@ -361,9 +363,7 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_shared_kernel(const
       for (int j = 0; j < NTILE; ++j)
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp)
-          acc[j][grp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              __builtin_bit_cast(bf16x8_t, wq[WPIPE ? (i & 1) : 0][j]),
-              __builtin_bit_cast(bf16x8_t, tap[grp][i >> 1][i & 1]), acc[j][grp], 0, 0, 0);
+          acc[j][grp] = mfma_16x16x32<H>(wq[WPIPE ? (i & 1) : 0][j], tap[grp][i >> 1][i & 1], acc[j][grp]);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -384,8 +384,8 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_shared_kernel(const
                       acc[2 * u + 1][grp][0], acc[2 * u + 1][grp][1], acc[2 * u + 1][grp][2], acc[2 * u + 1][grp][3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e], lo, hi);
-        store16_nt(py + 32 * u, pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                   pack_bf16x2(v[6], v[7]));
+        store16_nt(py + 32 * u, Half16<H>::pack2(v[0], v[1]), Half16<H>::pack2(v[2], v[3]),
+                   Half16<H>::pack2(v[4], v[5]), Half16<H>::pack2(v[6], v[7]));
       }
     }
   };
@@ -416,12 +416,12 @@ __global__ void __launch_bounds__(kC3Waves * 64) conv3x3_c64_shared_kernel(const
 }
 
 // SHARED: 0 = every tap loaded, 1 / 2 = taps shared between lanes at that stride
-template <int C1P, int SHARED>
+template <typename H, int C1P, int SHARED>
 static int launch_conv3(const Conv3Args& a, hipStream_t stream) {
   constexpr size_t smem = (size_t)2 * C1P * kC3Steps * 1024 + 32 * C1P * 4;
   static_assert(smem <= 160 * 1024, "filter too large for LDS");
-  auto kern = SHARED == 1 ? conv3x3_c64_shared_kernel<C1P, 1>
-              : SHARED == 2 ? conv3x3_c64_shared_kernel<C1P, 2> : conv3x3_c64_kernel<C1P>;
+  auto kern = SHARED == 1 ? conv3x3_c64_shared_kernel<H, C1P, 1>
+              : SHARED == 2 ? conv3x3_c64_shared_kernel<H, C1P, 2> : conv3x3_c64_kernel<H, C1P>;
   static bool attr_set = false;   // per instantiation
   if (smem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -466,7 +466,7 @@ extern "C" int fss_conv3x3_c64_nhwc(const void* x, int x_ld, const void* w, cons
                                     int dilation, int pad_top, int pad_left, int act, int dtype,
                                     void* stream) {
   FSS_REQUIRE(x && w && y, "null argument");
-  FSS_REQUIRE(dtype == FSS_BF16, "only bfloat16 is supported");
+  FSS_REQUIRE(dtype == FSS_BF16 || dtype == FSS_F16, "only bfloat16 and half precision are supported");
   FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0, "bad shape");
   FSS_REQUIRE(cout == 64 || cout == 128, "cout must be 64 or 128");
   FSS_REQUIRE(stride >= 1 && stride <= 4 && dilation >= 1 && dilation <= 8, "bad stride / dilation");
@@ -487,7 +487,12 @@ extern "C" int fss_conv3x3_c64_nhwc(const void* x, int x_ld, const void* w, cons
   hipStream_t s = (hipStream_t)stream;
   // stride 1, dilation 1: horizontal taps shared between lanes
   const int shared = dilation == 1 && stride <= 2 && getenv("FSS_C3_PLAIN") == nullptr ? stride : 0;
-  if (shared == 1) return cout == 64 ? launch_conv3<2, 1>(a, s) : launch_conv3<4, 1>(a, s);
-  if (shared == 2) return cout == 64 ? launch_conv3<2, 2>(a, s) : launch_conv3<4, 2>(a, s);
-  return cout == 64 ? launch_conv3<2, 0>(a, s) : launch_conv3<4, 0>(a, s);
+  if (dtype == FSS_F16) {
+    if (shared == 1) return cout == 64 ? launch_conv3<f16_t, 2, 1>(a, s) : launch_conv3<f16_t, 4, 1>(a, s);
+    if (shared == 2) return cout == 64 ? launch_conv3<f16_t, 2, 2>(a, s) : launch_conv3<f16_t, 4, 2>(a, s);
+    return cout == 64 ? launch_conv3<f16_t, 2, 0>(a, s) : launch_conv3<f16_t, 4, 0>(a, s);
+  }
+  if (shared == 1) return cout == 64 ? launch_conv3<bf16_t, 2, 1>(a, s) : launch_conv3<bf16_t, 4, 1>(a, s);
+  if (shared == 2) return cout == 64 ? launch_conv3<bf16_t, 2, 2>(a, s) : launch_conv3<bf16_t, 4, 2>(a, s);
+  return cout == 64 ? launch_conv3<bf16_t, 2, 0>(a, s) : launch_conv3<bf16_t, 4, 0>(a, s);
 }

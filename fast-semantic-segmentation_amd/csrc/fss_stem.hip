@@ -452,7 +452,8 @@ using namespace fss;
 
 extern "C" int fss_stem_pack_dims(int kh, int kw, int cout, int dtype, int* k_pad, int* cout_pad) {
   FSS_REQUIRE(k_pad && cout_pad, "null argument");
-  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F32_BF16X3, "bad dtype");
+  // (FSS_F16: the first layer of fss_stem2_conv_u8; same dimensions as bfloat16)
+  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F32_BF16X3 || dtype == FSS_F16, "bad dtype");
   FSS_REQUIRE(kh > 0 && kw > 0 && kh * kw <= 64 && cout > 0 && cout <= 64, "bad shape");
   const int k4 = kh * kw * 4;
   *k_pad = dtype != FSS_F32 ? (k4 + 31) / 32 * 32 : k4;

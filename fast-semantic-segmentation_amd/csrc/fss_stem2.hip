@@ -1,5 +1,6 @@
 // The first TWO convolutions of a full-resolution branch, fed straight from the
-// uint8 frame, in one kernel (gfx950, bf16).
+// uint8 frame, in one kernel (gfx950; bfloat16 or half precision, named by the kernel's template
+// parameter H: the two differ in the MFMA instruction and in the roundings only).
 //
 // ICNet's high-resolution branch (architectures/icnet_architecture.py:213-226 in the
 // reference) starts with 3x3 stride-2 convolutions on the 1025x2049 frame.  The
@@ -106,9 +107,10 @@ template <int KS1, int TH2> struct Stem2Lds {
 };
 
 // KS1 = C1 / 32, CW = C2 / 32, TH2 = output rows per tile, NW = waves of each kind per block
-template <int KS1, int CW, int TH2, int NW>
+template <typename H, int KS1, int CW, int TH2, int NW>
 __global__ void __launch_bounds__(2 * NW * 64) __attribute__((amdgpu_waves_per_eu(2)))
 stem2_conv_kernel(const Stem2Args a) {
+  typedef Half16<H> HH;
   constexpr int NT = NW * 64;                // threads of each kind
   constexpr int R1 = 2 * TH2 + 1;            // y1 rows of a tile
   constexpr int PH = 2 * R1 + 1;             // patch rows
@@ -162,8 +164,8 @@ stem2_conv_kernel(const Stem2Args a) {
         v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(a.w1) + ((size_t)co * kS2K4 * 2 + tap * 8));
       } else if (st == 1 && sg == 0) {
         const float b = a.b1[co];
-        const unsigned hi = f32_to_bf16(b);
-        const unsigned lo = f32_to_bf16(b - bf16_to_f32((bf16_t)hi));
+        const unsigned hi = HH::bits(b);
+        const unsigned lo = HH::bits(b - HH::value(hi));
         v.x = hi | (lo << 16);
       }
       *reinterpret_cast<uint2*>(wl + co * kS2WRow + (32 * st + 8 * sg + 4 * half) * 2) = v;
@@ -194,7 +196,7 @@ stem2_conv_kernel(const Stem2Args a) {
   // column parity (its weights are zero: any finite value will do)
   auto tap_off = [](int t) { return ((t / 3) * kS2PW + t % 3) * 8; };
   const int toA = tap_off(g), toB = tap_off(g + 4), toC = g == 0 ? tap_off(8) : (g & 1) * 8;
-  const unsigned one_pair = g == 0 ? 0x3f803f80u : 0u;   // B operand of the bias slots: 1.0, 1.0
+  const unsigned one_pair = g == 0 ? HH::kOnePair : 0u;   // B operand of the bias slots: 1.0, 1.0
 
   // ---- conv2 read offsets of this lane: pixel slot p + e (e = tap column >> 1), chunk 4*kh + g
   // (one per tap column s: plane s & 1, slot p + (s >> 1))
@@ -285,8 +287,8 @@ stem2_conv_kernel(const Stem2Args a) {
     auto store = [&](int k, bool slot, const float (&v)[3]) {
       if (slot) {
         uint2 o;
-        o.x = pack_bf16x2(v[0], v[1]);
-        o.y = pack_bf16x2(v[2], 0.f);
+        o.x = HH::pack2(v[0], v[1]);
+        o.y = HH::pack2(v[2], 0.f);
         *reinterpret_cast<uint2*>(patch + (size_t)(tid + NT * k) * 8) = o;
       }
     };
@@ -378,8 +380,7 @@ stem2_conv_kernel(const Stem2Args a) {
                                   : make_uint4(bc[u][2].x, bc[u][2].y, one_pair, 0u);
 #pragma unroll
           for (int nj = 0; nj < 2; ++nj)
-            acc[u][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w1f[st][nj]),
-                                                                 __builtin_bit_cast(bf16x8_t, b), acc[u][nj], 0, 0, 0);
+            acc[u][nj] = mfma_16x16x32<H>(w1f[st][nj], b, acc[u][nj]);
         }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -387,8 +388,8 @@ stem2_conv_kernel(const Stem2Args a) {
                       acc[u][1][0], acc[u][1][1], acc[u][1][2], acc[u][1][3]};
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = __builtin_amdgcn_fmed3f(v[q], lo1, hi1);
-        uint4 o = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                             pack_bf16x2(v[6], v[7]));
+        uint4 o = make_uint4(HH::pack2(v[0], v[1]), HH::pack2(v[2], v[3]), HH::pack2(v[4], v[5]),
+                             HH::pack2(v[6], v[7]));
         if (!y1_interior) {
           const int ci = (int)(ec[u].x >> 20), cj = (int)((ec[u].x >> 14) & 63u);
           const bool inside = (unsigned)(i1_0 + ci) < (unsigned)a.H1 && (unsigned)(j1_0 + cj) < (unsigned)a.W1;
@@ -452,11 +453,9 @@ stem2_conv_kernel(const Stem2Args a) {
         constexpr int t = i % PGW, kh = (i / PGW) % KS1, rs = i / (PGW * KS1);
         constexpr int younger = (i + RING - 1 < NB2 - 1 ? i + RING - 1 : NB2 - 1) - i;
         lds_wait<younger>(ring[i % RING]);
-        const u32x4_t b = ring[i % RING];
+        const uint4 b = __builtin_bit_cast(uint4, ring[i % RING]);
   #pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-          acc2[t][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-              __builtin_bit_cast(bf16x8_t, w2f[rs][kh][nj]), __builtin_bit_cast(bf16x8_t, b), acc2[t][nj], 0, 0, 0);
+        for (int nj = 0; nj < 2; ++nj) acc2[t][nj] = mfma_16x16x32<H>(w2f[rs][kh][nj], b, acc2[t][nj]);
         if constexpr (i + RING < NB2) issue(std::integral_constant<int, i + RING>{});
       };
       static_for<0, RING>(issue);
@@ -474,8 +473,8 @@ stem2_conv_kernel(const Stem2Args a) {
           unsigned o[4];
   #pragma unroll
           for (int e = 0; e < 4; ++e)
-            o[e] = pack_bf16x2(__builtin_amdgcn_fmed3f(v[2 * e], lo2, hi2),
-                               __builtin_amdgcn_fmed3f(v[2 * e + 1], lo2, hi2));
+            o[e] = HH::pack2(__builtin_amdgcn_fmed3f(v[2 * e], lo2, hi2),
+                             __builtin_amdgcn_fmed3f(v[2 * e + 1], lo2, hi2));
           bf16_t* dst = reinterpret_cast<bf16_t*>(a.y) +
                         (((size_t)now.n * a.H2 + oh) * a.W2 + ow) * a.y_ld + 32 * ch + 8 * g;
           store16_nt(dst, o[0], o[1], o[2], o[3]);
@@ -502,7 +501,7 @@ stem2_conv_kernel(const Stem2Args a) {
   }
 }
 
-template <int KS1, int CW, int TH2, int NW>
+template <typename H, int KS1, int CW, int TH2, int NW>
 static int launch_stem2(const Stem2Args& a0, hipStream_t stream) {
   Stem2Args a = a0;
   constexpr size_t smem = Stem2Lds<KS1, TH2>::BYTES;
@@ -515,7 +514,7 @@ static int launch_stem2(const Stem2Args& a0, hipStream_t stream) {
     return 2;
   }
   a.total_tiles = (int)total;
-  auto kern = stem2_conv_kernel<KS1, CW, TH2, NW>;
+  auto kern = stem2_conv_kernel<H, KS1, CW, TH2, NW>;
   static bool attr_set = false;   // per instantiation
   if (smem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -561,7 +560,7 @@ extern "C" int fss_stem2_conv_u8(const uint8_t* x, const void* w1_packed, const 
                                  int pad_top2, int pad_left2, int h2, int w2, int act2, int dtype,
                                  int y_ld, void* stream) {
   FSS_REQUIRE(x && w1_packed && bias1 && w2_packed && bias2 && y && mean3 && scale3, "null argument");
-  FSS_REQUIRE(dtype == FSS_BF16, "only bfloat16 is supported");
+  FSS_REQUIRE(dtype == FSS_BF16 || dtype == FSS_F16, "only bfloat16 and half precision are supported");
   FSS_REQUIRE(n > 0 && hr > 0 && wr > 0 && h > 0 && w > 0 && h1 > 0 && w1 > 0 && h2 > 0 && w2 > 0, "bad shape");
   FSS_REQUIRE(sub >= 1 && sub <= 8, "sub must be in [1, 8]");
   FSS_REQUIRE((long long)hr * wr * 3 >= 4, "frame too small");
@@ -597,10 +596,18 @@ extern "C" int fss_stem2_conv_u8(const uint8_t* x, const void* w1_packed, const 
   a.unit_scale = scale3[0] == 1.f && scale3[1] == 1.f && scale3[2] == 1.f;
   hipStream_t s = (hipStream_t)stream;
   // tiles of 4 x 16 output pixels, 4 + 4 waves: one block per CU
+  if (dtype == FSS_F16) {
+    switch ((c1 / 32) * 10 + c2 / 32) {
+      case 11: return launch_stem2<f16_t, 1, 1, 4, 4>(a, s);
+      case 12: return launch_stem2<f16_t, 1, 2, 4, 4>(a, s);
+      case 21: return launch_stem2<f16_t, 2, 1, 4, 4>(a, s);
+      default: return launch_stem2<f16_t, 2, 2, 4, 4>(a, s);
+    }
+  }
   switch ((c1 / 32) * 10 + c2 / 32) {
-    case 11: return launch_stem2<1, 1, 4, 4>(a, s);
-    case 12: return launch_stem2<1, 2, 4, 4>(a, s);
-    case 21: return launch_stem2<2, 1, 4, 4>(a, s);
-    default: return launch_stem2<2, 2, 4, 4>(a, s);
+    case 11: return launch_stem2<bf16_t, 1, 1, 4, 4>(a, s);
+    case 12: return launch_stem2<bf16_t, 1, 2, 4, 4>(a, s);
+    case 21: return launch_stem2<bf16_t, 2, 1, 4, 4>(a, s);
+    default: return launch_stem2<bf16_t, 2, 2, 4, 4>(a, s);
   }
 }

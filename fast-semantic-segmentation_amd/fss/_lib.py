@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get('FSS_LIB') or os.path.join(os.path.dirname(_HERE), 'li
 
 F32, BF16 = 0, 1
 F32_BF16X3 = 2      # fss_conv_desc.in_dtype only: float storage, split-bf16 products
+F16 = 3             # IEEE half precision tensors (convolution entry points only)
 PYRAMID_STATIC_MAX_BYTES = 32 << 20     # FSS_PYRAMID_STATIC_MAX_BYTES
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 ACT_CODES = {None: ACT_NONE, 'relu': ACT_RELU, 'relu6': ACT_RELU6}

@@ -33,10 +33,22 @@ import torch
 from fss import _lib
 from fss._lib import lib, check
 
-_TORCH_DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'u8': torch.uint8}
-_CODE = {'f32': _lib.F32, 'bf16': _lib.BF16}
-_EPC = {'f32': 4, 'bf16': 8}
-_ESZ = {'f32': 4, 'bf16': 2, 'u8': 1}
+_TORCH_DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16, 'u8': torch.uint8}
+_CODE = {'f32': _lib.F32, 'bf16': _lib.BF16, 'f16': _lib.F16}
+_EPC = {'f32': 4, 'bf16': 8, 'f16': 8}
+_ESZ = {'f32': 4, 'bf16': 2, 'f16': 2, 'u8': 1}
+
+# Convolutions (by the scope of their `weights` variable) that the 'mixed' mode computes in half
+# precision: the 3x3 convolution of every ResNet bottleneck unit (conv2,
+# third_party/dilated_resnet_v1.py:95-97) and the four convolutions of ICNet's full-resolution
+# branch (architectures/icnet_architecture.py:213-226).  Chosen on the float32 oracle and on the
+# GPU with one group of convolutions at a time in half precision (tools/precision_emulation.py,
+# tools/mixed_parity.py, tools/mixed_taps.py): these move the argmax labels least per millisecond
+# they save (full-size ICNet-1.0: conv2 of blocks 1+2 / 3 / 4 flip 0.020 / 0.030 / 0.013 % of the
+# labels, the branch 0.022 %, all together 0.037 %).  The residual stream of the blocks, the 1x1
+# convolutions that read or write it and the whole head stay float with split-bf16 products:
+# half precision there costs two to three times as many labels for a fifth of the time saved.
+DEFAULT_HALF_SCOPES = (r'/bottleneck_v1/conv2$', r'^Conv(_[123])?$')
 
 
 def f32_to_bf16_bits(a):
@@ -44,6 +56,12 @@ def f32_to_bf16_bits(a):
     u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
     u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
     return u.astype(np.uint16)
+
+
+def f32_to_f16_bits(a):
+    """float32 ndarray -> uint16 ndarray of IEEE half bits (round to nearest even, saturating)."""
+    a = np.clip(np.ascontiguousarray(a, dtype=np.float32), -65504.0, 65504.0)
+    return a.astype(np.float16).view(np.uint16)
 
 
 def f32_split_bf16_rows(wp):
@@ -131,14 +149,22 @@ class CompiledGraph(object):
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
                  fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True, fuse_chain=True, commute_pyramid=None, resident_3x3=True,
                  fuse_head=True, collapse_zooms=True, commute_zoom=None, fuse_zoom_residual=None,
-                 ksplit=False):
+                 ksplit=False, half_scopes=None):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         # 'float32x3': float32 tensors everywhere; the convolutions form their products on the
         # bf16 matrix pipe from bf16 hi/lo splits of both operands (FSS_F32_BF16X3)
-        self.split = dtype in ('float32x3', 'f32x3')
+        # 'mixed': float32x3, except that the convolutions named by `half_scopes` (regular
+        # expressions searched in the scope of a convolution's weights; DEFAULT_HALF_SCOPES) run
+        # on half-precision tensors with one f16 MFMA per product.  A tensor is stored in half
+        # precision when every consumer is such a convolution; a convolution computes in the type
+        # its input is stored in.
+        self.mixed = dtype == 'mixed'
+        self.split = dtype in ('float32x3', 'f32x3', 'mixed')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16',
-                   'float32x3': 'f32', 'f32x3': 'f32'}[dtype]
+                   'float32x3': 'f32', 'f32x3': 'f32', 'mixed': 'f32'}[dtype]
+        import re
+        self.half_re = [re.compile(p) for p in (DEFAULT_HALF_SCOPES if half_scopes is None else half_scopes)]
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
         self.weights = weights
         self.outputs = list(outputs)
@@ -265,6 +291,48 @@ class CompiledGraph(object):
     def _in_code(self, dt):
         """in_dtype code of a convolution whose input is stored as `dt`."""
         return _lib.F32_BF16X3 if (dt == 'f32' and self.split) else _CODE[dt]
+
+    def _pack(self, Wp, dt):
+        """Packed float32 weight matrix -> device tensor in the form a convolution reading `dt`
+        tensors takes (bf16 / f16 bits; float, or its split-bf16 rows in the float32x3 modes)."""
+        if dt == 'bf16':
+            dev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+        elif dt == 'f16':
+            dev = torch.from_numpy(f32_to_f16_bits(Wp).view(np.int16)).to(self.device)
+        elif self.split:
+            dev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
+        else:
+            dev = torch.from_numpy(np.ascontiguousarray(Wp, np.float32)).to(self.device)
+        self.keepalive.append(dev)
+        return dev
+
+    def _is_half_conv(self, ln):
+        if not self.mixed or ln.kind != 'conv2d':
+            return False
+        scope = ln.attrs['weights'].rsplit('/', 1)[0]
+        return any(r.search(scope) for r in self.half_re)
+
+    def _store_dt(self, result, in_dt):
+        """Storage type of the tensor `result` a convolution reading `in_dt` tensors produces.
+        Outside the mixed mode: the input's.  Mixed mode: half precision when every consumer is a
+        half-precision convolution, or the residual add that such a convolution absorbs."""
+        if not self.mixed:
+            return in_dt
+        if result.is_output or not result.consumers:
+            return 'f32'
+        for c in result.consumers:
+            if c.kind == 'conv2d' and c.inputs[0] is result and self._is_half_conv(c):
+                continue
+            if c.kind == 'add' and len(c.inputs) == 2:
+                # a residual: the half-precision convolution that absorbs the add reads it in the
+                # type it stores its own result in
+                other = c.inputs[0] if c.inputs[1] is result else c.inputs[1]
+                if other is not result and self._is_half_conv(other) and other.pos > result.pos:
+                    total = self._only_consumer(c, 'relu') or c
+                    if self._store_dt(total, 'f16') == 'f16':
+                        continue
+            return 'f32'
+        return 'f16'
 
     def _dev_f32(self, arr):
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
@@ -414,28 +482,30 @@ class CompiledGraph(object):
         Wt = self.weights[a['weights']].astype(np.float64) * scale      # [kh,kw,3,cout]
         Wt = np.pad(Wt, ((0, 0), (0, 0), (0, 1), (0, 0)))
         k_pad, cout_pad = ctypes.c_int(0), ctypes.c_int(0)
-        code = self._in_code(self.dt)
+        nxt, dt2 = self._stem2_partner(ln)
+        code = _CODE[dt2] if nxt is not None else self._in_code(self.dt)
         _lib.call('fss_stem_pack_dims', kh, kw, cout, code, ctypes.byref(k_pad),
                   ctypes.byref(cout_pad))
         Wp = np.zeros((cout_pad.value, k_pad.value), np.float32)
         Wp[:cout, :kh * kw * 4] = Wt.transpose(3, 0, 1, 2).reshape(cout, -1)
-        if self.dt == 'bf16':
-            wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
+        if nxt is not None:
+            wdev = self._pack(Wp, dt2)
+        elif self.dt == 'bf16':
+            wdev = self._pack(Wp, 'bf16')
         elif self.split:
             # two bf16 matrices: high parts, then remainders
             hi = f32_to_bf16_bits(Wp)
             lo = f32_to_bf16_bits(Wp - (hi.astype(np.uint32) << 16).view(np.float32))
             wdev = torch.from_numpy(np.concatenate([hi, lo]).view(np.int16)).to(self.device)
+            self.keepalive.append(wdev)
         else:
-            wdev = torch.from_numpy(Wp).to(self.device)
-        self.keepalive.append(wdev)
+            wdev = self._pack(Wp, 'f32')
         bdev = self._dev_f32(bias)
         self.param_bytes += cout * kh * kw * 3 * _ESZ[self.dt]
         mean = (ctypes.c_float * 3)(*pre.attrs['mean'])
         sc = (ctypes.c_float * 3)(*pre.attrs['scale'])
-        nxt = self._stem2_partner(ln)
         if nxt is not None:
-            return self._l_stem2_conv(ln, nxt, x, sub, h, w, wdev, bdev, mean, sc)
+            return self._l_stem2_conv(ln, nxt, x, sub, h, w, wdev, bdev, mean, sc, dt2)
         out = Val(self._alloc(ln.shape, self.dt), ln.shape, self.dt)
         self.vals[ln] = out
         self._emit('stem', a['weights'].rsplit('/', 1)[0], 'fss_stem_conv_u8',
@@ -447,35 +517,39 @@ class CompiledGraph(object):
                    keep=(mean, sc))
 
     def _stem2_partner(self, ln):
-        """The convolution that consumes stem conv `ln` when both can run as one
-        fss_stem2_conv_u8 launch (3x3, stride 2, batch norm, 32 or 64 channels, bfloat16),
-        so that the output of `ln` never reaches memory."""
+        """(the convolution that consumes stem conv `ln`, the 16-bit type) when both can run as
+        one fss_stem2_conv_u8 launch (3x3, stride 2, batch norm, 32 or 64 channels; bfloat16, or
+        half precision where the mixed mode puts both layers and their consumers), so that the
+        output of `ln` never reaches memory; (None, None) otherwise."""
         def shape_ok(c):
             a = c.attrs
             return ((a['kh'], a['kw'], a['stride'], a['rate']) == (3, 3, 2, 1) and a['biases'] is None
                     and c.shape[3] in (32, 64) and a['pad_top'] <= 2 and a['pad_left'] <= 2)
-        if not self.fuse_stem2 or self.dt != 'bf16' or not shape_ok(ln):
-            return None
+        if not self.fuse_stem2 or not (self.dt == 'bf16' or self.mixed) or not shape_ok(ln):
+            return None, None
         nxt = self._only_consumer(ln, 'conv2d')
         if nxt is None or not shape_ok(nxt) or self._only_consumer(nxt, 'add') is not None:
-            return None
-        return nxt
+            return None, None
+        if self.dt == 'bf16':
+            return nxt, 'bf16'
+        if self._is_half_conv(ln) and self._is_half_conv(nxt) and self._store_dt(nxt, 'f16') == 'f16':
+            return nxt, 'f16'
+        return None, None
 
-    def _l_stem2_conv(self, ln, nxt, x, sub, h, w, w1dev, b1dev, mean, sc):
+    def _l_stem2_conv(self, ln, nxt, x, sub, h, w, w1dev, b1dev, mean, sc, dt):
         a1, a2 = ln.attrs, nxt.attrs
         n, hr, wr, _ = x.shape
         _, h1, w1, c1 = ln.shape
         _, h2, w2, c2 = nxt.shape
         scale, bias = self._fold_bn(a2, c2)
         Wt = self.weights[a2['weights']].astype(np.float64) * scale      # [3,3,c1,c2]
-        k_pad, cout_pad = _lib.conv_pack_dims(c1, 3, 3, c2, _CODE[self.dt])
+        k_pad, cout_pad = _lib.conv_pack_dims(c1, 3, 3, c2, _CODE[dt])
         Wp = np.zeros((cout_pad, k_pad), np.float32)
         Wp[:c2, :9 * c1] = Wt.transpose(3, 0, 1, 2).reshape(c2, -1)
-        w2dev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
-        self.keepalive.append(w2dev)
+        w2dev = self._pack(Wp, dt)
         b2dev = self._dev_f32(bias)
-        self.param_bytes += c2 * 9 * c1 * _ESZ[self.dt]
-        out = Val(self._alloc(nxt.shape, self.dt), nxt.shape, self.dt)
+        self.param_bytes += c2 * 9 * c1 * _ESZ[dt]
+        out = Val(self._alloc(nxt.shape, dt), nxt.shape, dt)
         self.vals[nxt] = out
         self.fused.add(nxt)
         self._emit('stem2', a2['weights'].rsplit('/', 1)[0], 'fss_stem2_conv_u8',
@@ -483,9 +557,9 @@ class CompiledGraph(object):
                     n, hr, wr, sub, h, w, mean, sc,
                     c1, a1['pad_top'], a1['pad_left'], h1, w1, _lib.ACT_CODES[a1['activation']],
                     c2, a2['pad_top'], a2['pad_left'], h2, w2, _lib.ACT_CODES[a2['activation']],
-                    _CODE[self.dt], out.ld, self.sh),
+                    _CODE[dt], out.ld, self.sh),
                    flops=2 * n * (h1 * w1 * c1 * 27 + h2 * w2 * c2 * 9 * c1),
-                   nbytes=n * (hr // sub) * (wr // sub) * 3 + n * h2 * w2 * c2 * _ESZ[self.dt],
+                   nbytes=n * (hr // sub) * (wr // sub) * 3 + n * h2 * w2 * c2 * _ESZ[dt],
                    keep=(mean, sc))
 
     def _dual_partner(self, ln):
@@ -509,6 +583,8 @@ class CompiledGraph(object):
             return None
         if ln.inputs[0].shape[3] % 64 or A.inputs[0].shape[3] % 64:
             return None
+        if self._is_half_conv(ln) != self._is_half_conv(A):
+            return None        # mixed mode: the two inputs would differ in type
         return A
 
     def _chain_partner(self, result, k, cout, dt):
@@ -664,14 +740,7 @@ class CompiledGraph(object):
             k_pad, cout_pad = (k + 63) // 64 * 64, (cout + 255) // 256 * 256
             Wp = np.zeros((cout_pad, k_pad), np.float32)
             Wp[:cout, :k] = Wt
-            if dt == 'bf16':
-                dev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
-            elif self.split:
-                dev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
-            else:
-                dev = torch.from_numpy(Wp).to(self.device)
-            self.keepalive.append(dev)
-            return dev, k_pad, cout_pad
+            return self._pack(Wp, dt), k_pad, cout_pad
 
         WB = (self.weights[b['weights']].astype(np.float64) * sB).transpose(3, 0, 1, 2).reshape(cout, -1)
         wB, k_pad, cout_pad = pack(WB, 9 * cin)
@@ -770,13 +839,7 @@ class CompiledGraph(object):
         Wp = np.zeros((cout_pad, k_pad), np.float32)
         Wp[:cout, :kh * kw * cin] = WB.transpose(3, 0, 1, 2).reshape(cout, -1)
         Wp[:cout, kh * kw * cin:k] = WA.reshape(cin2, cout).T
-        if x.dt == 'bf16':
-            wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
-        elif self.split:
-            wdev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
-        else:
-            wdev = torch.from_numpy(Wp).to(self.device)
-        self.keepalive.append(wdev)
+        wdev = self._pack(Wp, x.dt)
         bdev = self._dev_f32(bA + bB)
         self.param_bytes += cout * k * _ESZ[x.dt]
         name = b['weights'].rsplit('/', 1)[0] + '+' + A.attrs['weights'].rsplit('/', 2)[-2]
@@ -791,14 +854,16 @@ class CompiledGraph(object):
                               ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=self._in_code(x.dt),
                               out_dtype=_CODE[x.dt], y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
             return self._emit_head(head, d, x, x2, cin2, wdev, bdev, cout, k, name)
-        out = Val(self._alloc(B.shape, x.dt), B.shape, x.dt)
+        out_dt = self._store_dt(result, x.dt)
+        out = Val(self._alloc(B.shape, out_dt), B.shape, out_dt)
         for node in (A, B, add, result):
             self.vals[node] = out
         d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
                           dilation=b['rate'], pad_top=b['pad_top'], pad_left=b['pad_left'],
                           ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=self._in_code(x.dt),
-                          out_dtype=_CODE[x.dt], y_ld=out.ld, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
-        nbytes = (n * h * w * cin + n * ho * wo * cin2 + cout * k + n * ho * wo * cout) * _ESZ[x.dt]
+                          out_dtype=_CODE[out_dt], y_ld=out.ld, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
+        nbytes = ((n * h * w * cin + n * ho * wo * cin2 + cout * k) * _ESZ[x.dt]
+                  + n * ho * wo * cout * _ESZ[out_dt])
         self._emit('conv', name, 'fss_conv2d_dual_nhwc',
                    (ctypes.byref(d), x.ptr, x2.ptr, cin2, wdev.data_ptr(), bdev.data_ptr(), None,
                     out.ptr, self.sh),
@@ -846,13 +911,7 @@ class CompiledGraph(object):
         k_pad, cout_pad = _lib.conv_pack_dims(cin, 1, 1, cout, _CODE[dt])
         Wp = np.zeros((cout_pad, k_pad), np.float32)
         Wp[:cout, :cin] = Wt.reshape(cin, cout).T
-        if dt == 'bf16':
-            wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
-        elif self.split:
-            wdev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
-        else:
-            wdev = torch.from_numpy(Wp).to(self.device)
-        self.keepalive.append(wdev)
+        wdev = self._pack(Wp, dt)
         bdev = self._dev_f32(bias)
         self.param_bytes += cout * cin * _ESZ[dt]
         name = a['weights'].rsplit('/', 1)[0]
@@ -911,22 +970,25 @@ class CompiledGraph(object):
         _, ho, wo, cout = ln.shape
         kh, kw = a['kh'], a['kw']
         in_dt = x.dt
-        out_dt = 'f32' if a['biases'] is not None else in_dt    # logits stay float32
         act = a['activation']
         res, result = None, ln
         add = self._only_consumer(ln, 'add')
-        if add is not None and act is None and out_dt == in_dt:
+        if add is not None and act is None and a['biases'] is None:
             other = [y for y in add.inputs if y is not ln]
             other = other[0] if other else None
             if other is not None and other.pos < ln.pos:
                 ov = self._val(other)
-                if ov.dt == in_dt:
+                total = self._only_consumer(add, 'relu') or add
+                # the residual's type: the input's; for half-precision input, the output's
+                want = self._store_dt(total, in_dt) if in_dt == 'f16' else in_dt
+                if ov.dt == want:
                     res, result = ov, add
                     self.fused.add(add)
-                    relu = self._only_consumer(add, 'relu')
-                    if relu is not None:
-                        act, result = 'relu', relu
-                        self.fused.add(relu)
+                    if total is not add:
+                        act, result = 'relu', total
+                        self.fused.add(total)
+        # logits stay float32; otherwise the input's type (mixed mode: what the consumers read)
+        out_dt = 'f32' if a['biases'] is not None else self._store_dt(result, in_dt)
         scale, bias = self._fold_bn(a, cout)
         Wt = self.weights[a['weights']].astype(np.float64) * scale      # [kh,kw,cin,cout]
         pc = x.phys_c
@@ -935,13 +997,7 @@ class CompiledGraph(object):
         k_pad, cout_pad = _lib.conv_pack_dims(pc, kh, kw, cout, _CODE[in_dt])
         Wp = np.zeros((cout_pad, k_pad), np.float32)
         Wp[:cout, :kh * kw * pc] = Wt.transpose(3, 0, 1, 2).reshape(cout, -1)
-        if in_dt == 'bf16':
-            wdev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
-        elif self.split:
-            wdev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
-        else:
-            wdev = torch.from_numpy(Wp).to(self.device)
-        self.keepalive.append(wdev)
+        wdev = self._pack(Wp, in_dt)
         bdev = self._dev_f32(bias)
         self.param_bytes += cout * kh * kw * cin * _ESZ[in_dt]
         if ((kh, kw, a['stride'], a['rate'], a['pad_top'], a['pad_left']) == (1, 1, 1, 1, 0, 0) and pc == cin
@@ -952,8 +1008,8 @@ class CompiledGraph(object):
                 nodes = (ln,) if result is ln else ((ln, add, result) if result is not add else (ln, add))
                 return self._emit_chain(nxt, nodes, x, None, Wp[:cout, :cin], bias, res, act,
                                         a['weights'].rsplit('/', 1)[0])
-        if (self.resident_3x3 and (kh, kw) == (3, 3) and pc == cin == 64 and cout in (64, 128) and in_dt == 'bf16'
-                and out_dt == in_dt and res is None and a['biases'] is None and h * w * x.ld < 2 ** 31
+        if (self.resident_3x3 and (kh, kw) == (3, 3) and pc == cin == 64 and cout in (64, 128)
+                and in_dt in ('bf16', 'f16') and out_dt == in_dt and res is None and a['biases'] is None and h * w * x.ld < 2 ** 31
                 and (cout == 128 or a['stride'] == 2 or (a['stride'], a['rate']) == (1, 1))):
             # 64 input channels: the filter stays in LDS, the activations go straight to the MFMAs
             # (measured faster than the implicit GEMM for 128 filters and for stride 2: `Conv_2`
@@ -1301,18 +1357,24 @@ class CompiledGraph(object):
         cache = CompiledGraph._TUNE_CACHE
         ncfg = lib.fss_conv_config_count()
         info = (ctypes.c_int * 7)()
-        candidates, tile_n = [], {}
+        # candidates of the plan's MFMA shape; the split-bf16 launches take only those with an
+        # even number of k steps per tile
+        all_cands, split_cands, tile_n = [], [], {}
+        small_all, small_split = [], []
         for cfg in range(1, ncfg + 1):
             _lib.call('fss_conv_config_info', cfg, info)
-            if info[6] == self.mfma_edge and not (self.split and (info[4] // (16 * (64 // info[6]))) % 2):
-                candidates.append(cfg)
-                tile_n[cfg] = info[1]
-        # small-tile configurations: the ones a split-K launch is tried with
-        small = []
-        for cfg in candidates:
-            _lib.call('fss_conv_config_info', cfg, info)
+            if info[6] != self.mfma_edge:
+                continue
+            even = (info[4] // (16 * (64 // info[6]))) % 2 == 0
+            all_cands.append(cfg)
+            tile_n[cfg] = info[1]
+            if even:
+                split_cands.append(cfg)
+            # small-tile configurations: the ones a split-K launch is tried with
             if info[0] * info[1] <= 128 * 64:
-                small.append(cfg)
+                small_all.append(cfg)
+                if even:
+                    small_split.append(cfg)
         e0 = e1 = None
         ms = ctypes.c_float()
         tune_ws = None
@@ -1321,6 +1383,8 @@ class CompiledGraph(object):
                 continue
             d = s.keep[0] if isinstance(s.keep, tuple) else s.keep
             key = ','.join(str(getattr(d, f[0])) for f in d._fields_ if f[0] != 'config')
+            x3 = d.in_dtype == _lib.F32_BF16X3
+            candidates, small = (split_cands, small_split) if x3 else (all_cands, small_all)
             cands = candidates
             # split-K candidates: an output too small to fill the chip (at most four 64x64 tiles
             # per CU) under a long K axis, i.e. the late backbone blocks at one or two frames
@@ -1610,7 +1674,7 @@ class CompiledGraph(object):
         t = v.buf.reshape(v.buf.shape[0], v.buf.shape[1], v.buf.shape[2], -1)
         with torch.cuda.stream(self.stream):
             t = t[:, :h, :w, v.coff:v.coff + c]
-            if t.dtype == torch.bfloat16:
+            if t.dtype in (torch.bfloat16, torch.float16):
                 t = t.float()
             out = t.cpu()
         return out.numpy()

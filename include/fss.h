@@ -15,7 +15,8 @@
  *   - `stream` is a hipStream_t (NULL = the null stream); launches are
  *     asynchronous on it.  No entry point in the "kernels" section allocates,
  *     frees or synchronises, so a sequence of them can be stream-captured.
- *   - dtype codes: FSS_F32 = float, FSS_BF16 = bfloat16 (uint16 storage).
+ *   - dtype codes: FSS_F32 = float, FSS_BF16 = bfloat16 (uint16 storage), FSS_F16 = IEEE
+ *     half precision (uint16 storage; accepted where an entry point says so).
  */
 #ifndef FSS_H_
 #define FSS_H_
@@ -38,6 +39,14 @@ extern "C" {
  * of a row are stored as their 8 bf16 high parts followed by their 8 bf16 remainders.
  * Needs a tile configuration with an even number of k steps per tile. */
 #define FSS_F32_BF16X3 2
+/* IEEE half precision tensors (11 significant bits against bfloat16's 8, same bytes and the
+ * same matrix-core rate): every product is one f16 MFMA with float accumulation, outputs are
+ * rounded to nearest even and saturate at +-65504.  Taken by the convolution entry points
+ * that name it (fss_conv2d_nhwc and its dual / split-K forms, fss_conv3x3_c64_nhwc,
+ * fss_stem2_conv_u8); a convolution may also read FSS_F32_BF16X3 input and store FSS_F16
+ * output, or read FSS_F16 and store float, which is how half-precision stretches of a graph
+ * join the float ones. */
+#define FSS_F16 3
 
 #define FSS_ACT_NONE 0
 #define FSS_ACT_RELU 1
@@ -91,9 +100,10 @@ typedef struct fss_conv_desc {
   int32_t pad_top, pad_left; /* zero padding before the first row / column */
   int32_t ho, wo;            /* output spatial size                        */
   int32_t act;               /* FSS_ACT_*                                  */
-  int32_t in_dtype;          /* FSS_F32 | FSS_BF16 (x, weights, residual) |
+  int32_t in_dtype;          /* FSS_F32 | FSS_BF16 | FSS_F16 (x, weights, residual) |
                                 FSS_F32_BF16X3 (float storage, split-bf16 MFMA) */
-  int32_t out_dtype;         /* FSS_F32 | FSS_BF16                         */
+  int32_t out_dtype;         /* FSS_F32 (any input) | FSS_BF16 (bf16 input) |
+                                FSS_F16 (FSS_F16 or FSS_F32_BF16X3 input)   */
   int32_t y_ld;              /* output pixel stride in elements (>= cout)  */
   int32_t res_ld;            /* residual pixel stride in elements          */
   int32_t k_pad, cout_pad;   /* packed weight dims                         */
@@ -120,7 +130,8 @@ int fss_conv_config_info(int config, int info[7]);
  * architectures/pspnet_architecture.py:135,144) and, with `residual`, the
  * shortcut add + relu of third_party/dilated_resnet_v1.py:109, the add + relu of
  * architectures/icnet_architecture.py:251-252 and third_party/conv_blocks.py:313.
- * `residual` has the output's shape and the input dtype; NULL = none. */
+ * `residual` has the output's shape and the input dtype (FSS_F16 input: the OUTPUT dtype, so
+ * that a float residual stream can absorb a half-precision convolution); NULL = none. */
 int fss_conv2d_nhwc(const fss_conv_desc* desc, const void* x, const void* w_packed,
                     const float* bias, const void* residual, void* y, void* stream);
 

@@ -6,11 +6,21 @@ import numpy as np
 import torch
 
 from fss import _lib
-from fss.plan import f32_to_bf16_bits, f32_split_bf16_rows
+from fss.plan import f32_to_bf16_bits, f32_to_f16_bits, f32_split_bf16_rows
 
 # 'f32x3': float32 tensors; convolutions take them as FSS_F32_BF16X3 (split-bf16 products)
 DT = {'f32': (_lib.F32, torch.float32, 4), 'bf16': (_lib.BF16, torch.bfloat16, 8),
-      'f32x3': (_lib.F32, torch.float32, 4)}
+      'f32x3': (_lib.F32, torch.float32, 4), 'f16': (_lib.F16, torch.float16, 8)}
+
+
+def half_bits(a, dt):
+    """float32 array -> the uint16 bit patterns of its bfloat16 / half-precision rounding."""
+    return f32_to_f16_bits(a) if dt == 'f16' else f32_to_bf16_bits(a)
+
+
+def f16_round(a):
+    """float32 -> nearest half-precision value, as float32."""
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
 
 
 def conv_in_code(dt):
@@ -41,8 +51,8 @@ def pack_conv_weights(w, dt, cin_phys=None):
     k_pad, cout_pad = _lib.conv_pack_dims(pc, kh, kw, cout, DT[dt][0])
     wp = np.zeros((cout_pad, k_pad), np.float32)
     wp[:cout, :kh * kw * pc] = w.transpose(3, 0, 1, 2).reshape(cout, -1)
-    if dt == 'bf16':
-        dev = torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
+    if dt in ('bf16', 'f16'):
+        dev = torch.from_numpy(half_bits(wp, dt).view(np.int16)).cuda()
     elif dt == 'f32x3':
         dev = torch.from_numpy(f32_split_bf16_rows(wp).view(np.int16)).cuda()
     else:
@@ -61,7 +71,8 @@ def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw
     xd = to_dev(x, dt)
     wdev, k_pad, cout_pad = pack_conv_weights(w, dt)
     bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda() if bias is not None else None
-    rd = to_dev(residual, dt) if residual is not None else None
+    # the residual has the input's type; for half-precision input, the output's
+    rd = to_dev(residual, out_dt if dt == 'f16' else dt) if residual is not None else None
     ld = y_ld or cout
     y = torch.full((n, ho, wo, ld), -77.0, dtype=DT[out_dt][1], device='cuda')
     d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride,
@@ -89,7 +100,7 @@ def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw
 
 
 def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, act=None, dt='bf16',
-                config=0):
+                config=0, out_dt=None):
     """act(conv(x, w) + conv1x1(x2, w2) + bias) through fss_conv2d_dual_nhwc; host float32
     arrays in, float32 [n,ho,wo,cout] out."""
     n, h, wd, cin = x.shape
@@ -101,18 +112,19 @@ def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, 
     wp = np.zeros((cout_pad, k_pad), np.float32)
     wp[:cout, :kh * kw * cin] = w.transpose(3, 0, 1, 2).reshape(cout, -1)
     wp[:cout, kh * kw * cin:k] = w2.reshape(cin2, cout).T
-    if dt == 'bf16':
-        wdev = torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
+    if dt in ('bf16', 'f16'):
+        wdev = torch.from_numpy(half_bits(wp, dt).view(np.int16)).cuda()
     elif dt == 'f32x3':
         wdev = torch.from_numpy(f32_split_bf16_rows(wp).view(np.int16)).cuda()
     else:
         wdev = torch.from_numpy(wp).cuda()
     xd, x2d = to_dev(x, dt), to_dev(x2, dt)
     bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda()
-    y = torch.full((n, ho, wo, cout), -77.0, dtype=DT[dt][1], device='cuda')
+    out_dt = out_dt or dt
+    y = torch.full((n, ho, wo, cout), -77.0, dtype=DT[out_dt][1], device='cuda')
     d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride,
                       dilation=rate, pad_top=pads[0], pad_left=pads[1], ho=ho, wo=wo,
-                      act=_lib.ACT_CODES[act], in_dtype=conv_in_code(dt), out_dtype=DT[dt][0],
+                      act=_lib.ACT_CODES[act], in_dtype=conv_in_code(dt), out_dtype=DT[out_dt][0],
                       y_ld=cout, res_ld=0, k_pad=k_pad, cout_pad=cout_pad, config=config)
     torch.cuda.synchronize()
     _lib.call('fss_conv2d_dual_nhwc', ctypes.byref(d), xd.data_ptr(), x2d.data_ptr(), cin2,
@@ -205,22 +217,22 @@ def conv1x1_chain(x, x2, w, bias, residual, act1, w2, bias2, act2, y_ld=None, y2
     return o1[..., :cout1], o2[..., :cout2]
 
 
-def conv3x3_c64(x, w, bias, stride, rate, pads, out_hw, act, y_ld=None):
+def conv3x3_c64(x, w, bias, stride, rate, pads, out_hw, act, y_ld=None, dt='bf16'):
     """act(conv3x3(x, w) + bias) through fss_conv3x3_c64_nhwc (bfloat16, 64 input channels, filter
     resident in LDS).  x: [n,h,w,64]; w: [3,3,64,cout].  Returns float32 [n,ho,wo,cout]."""
     n, h, wd, cin = x.shape
     cout = w.shape[3]
     ho, wo = out_hw
-    wdev = torch.from_numpy(f32_to_bf16_bits(np.ascontiguousarray(w.transpose(3, 0, 1, 2).reshape(cout, -1)))
+    wdev = torch.from_numpy(half_bits(np.ascontiguousarray(w.transpose(3, 0, 1, 2).reshape(cout, -1)), dt)
                             .view(np.int16)).cuda()
-    xd = to_dev(x, 'bf16')
+    xd = to_dev(x, dt)
     bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda() if bias is not None else None
     ld = y_ld or cout
-    y = torch.full((n, ho, wo, ld), -77.0, dtype=torch.bfloat16, device='cuda')
+    y = torch.full((n, ho, wo, ld), -77.0, dtype=DT[dt][1], device='cuda')
     torch.cuda.synchronize()
     _lib.call('fss_conv3x3_c64_nhwc', xd.data_ptr(), cin, wdev.data_ptr(), bd.data_ptr() if bd is not None else None,
               y.data_ptr(), ld, n, h, wd, ho, wo, cout, stride, rate, pads[0], pads[1], _lib.ACT_CODES[act],
-              _lib.BF16, None)
+              DT[dt][0], None)
     _lib.call('fss_device_sync')
     out = to_host(y)
     assert np.all(out[..., cout:] == -77.0), 'wrote outside its channels'
@@ -269,8 +281,8 @@ def pack_stem_weights(w, dt):
     wp = np.zeros((cout_pad.value, k_pad.value), np.float32)
     w4 = np.pad(w, ((0, 0), (0, 0), (0, 1), (0, 0)))
     wp[:cout, :kh * kw * 4] = w4.transpose(3, 0, 1, 2).reshape(cout, -1)
-    if dt == 'bf16':
-        return torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
+    if dt in ('bf16', 'f16'):
+        return torch.from_numpy(half_bits(wp, dt).view(np.int16)).cuda()
     if dt == 'f32x3':       # high parts, then remainders
         hi = f32_to_bf16_bits(wp)
         lo = f32_to_bf16_bits(wp - (hi.astype(np.uint32) << 16).view(np.float32))
@@ -303,25 +315,25 @@ def stem_conv(frames, w, bias, mean, scale, sub, logical_hw, stride, rate, pads,
 
 
 def stem2_conv(frames, w1, b1, w2, b2, mean, scale, sub, logical_hw, pads1, hw1, act1, pads2, hw2, act2,
-               y_ld=None):
+               y_ld=None, dt='bf16'):
     """Two fused 3x3 stride-2 convolutions from uint8 frames [n,hr,wr,3] (bfloat16);
     returns the float32 host array [n,h2,w2,c2]."""
     n, hr, wr, _ = frames.shape
     c1, c2 = w1.shape[3], w2.shape[3]
     xd = torch.from_numpy(frames).cuda()
-    w1d = pack_stem_weights(w1, 'bf16')
-    w2d, _, _ = pack_conv_weights(w2, 'bf16')
+    w1d = pack_stem_weights(w1, dt)
+    w2d, _, _ = pack_conv_weights(w2, dt)
     b1d = torch.from_numpy(np.asarray(b1, np.float32)).cuda()
     b2d = torch.from_numpy(np.asarray(b2, np.float32)).cuda()
     ld = y_ld or c2
-    y = torch.full((n, hw2[0], hw2[1], ld), -77.0, dtype=torch.bfloat16, device='cuda')
+    y = torch.full((n, hw2[0], hw2[1], ld), -77.0, dtype=DT[dt][1], device='cuda')
     m3 = (ctypes.c_float * 3)(*mean)
     s3 = (ctypes.c_float * 3)(*scale)
     torch.cuda.synchronize()
     _lib.call('fss_stem2_conv_u8', xd.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), w2d.data_ptr(),
               b2d.data_ptr(), y.data_ptr(), n, hr, wr, sub, logical_hw[0], logical_hw[1], m3, s3,
               c1, pads1[0], pads1[1], hw1[0], hw1[1], _lib.ACT_CODES[act1],
-              c2, pads2[0], pads2[1], hw2[0], hw2[1], _lib.ACT_CODES[act2], _lib.BF16, ld, None)
+              c2, pads2[0], pads2[1], hw2[0], hw2[1], _lib.ACT_CODES[act2], DT[dt][0], ld, None)
     _lib.call('fss_device_sync')
     out = to_host(y)
     if ld != c2:

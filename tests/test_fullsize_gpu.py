@@ -121,7 +121,7 @@ def test_benchmarked_plan_at_full_size_matches_oracle(config, fs):
     epilogue with the interpolated residual, the two zooms are one and two streams are on -
     against the numpy oracle on its first and last frame: classifier scores (zoomed x2 on the
     host, which is where the reference applies the classifier) within the stated tolerance of
-    the dtype, labels as stated for float32x3 and as measured for bfloat16; and against the
+    the dtype, labels as stated for float32x3 and the mixed mode and as measured for bfloat16; and against the
     small-batch plan (fusion convolutions on the zoomed grid, stored residual)."""
     import bench
     from fss import plan
@@ -130,7 +130,7 @@ def test_benchmarked_plan_at_full_size_matches_oracle(config, fs):
     rng = np.random.default_rng(21)
     frames = rng.integers(0, 256, (B, 1024, 2048, 3)).astype(np.uint8)
     refs = {}
-    for dtype, tol, floor in (('bfloat16', 2e-2, 0.97), ('float32x3', 1e-3, 0.999)):
+    for dtype, tol, floor in (('bfloat16', 2e-2, 0.97), ('float32x3', 1e-3, 0.999), ('mixed', 1e-3, 0.999)):
         cg, pred, _, weights = bench.build_plan(B, dtype, config=config)
         names = [s.name for s in cg.steps]
         assert any(n.endswith('@source') for n in names), 'fusion convs must run at the source resolution'

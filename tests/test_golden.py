@@ -59,7 +59,7 @@ def test_oracle_matches_the_second_implementation(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', ['float32', 'float32x3', 'bfloat16'])
+@pytest.mark.parametrize('dtype', ['float32', 'float32x3', 'mixed', 'bfloat16'])
 @pytest.mark.parametrize('path', FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
 def test_hip_path_matches_the_second_implementation(path, dtype):
     from fss import plan

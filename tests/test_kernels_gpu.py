@@ -270,6 +270,9 @@ def test_conv2d_head_is_conv_then_classifier(cout, cin2, with_res, dt):
     (1, 21, 20, 128, 1, 2, 'SAME'),       # dilation 2
     (3, 40, 67, 64, 1, 1, 'SAME'),        # several passes per block, rows that wrap inside a pixel group
     (1, 3, 3, 64, 1, 1, 'SAME'),          # every tap of most pixels on the padding
+    (1, 40, 67, 128, 2, 1, 'SAME'),       # rows of 34 outputs at stride 2: groups that do not wrap,
+    (2, 21, 70, 64, 2, 1, 'SAME'),        # i.e. tap 2 taken from the next lane (DPP), 64 and 128 filters
+    (2, 19, 40, 128, 1, 1, 'SAME'),       # 128 filters at stride 1, dilation 1 (no weight pipelining)
 ])
 def test_conv3x3_c64_matches_oracle(n, h, wd, cout, stride, rate, mode):
     """fss_conv3x3_c64_nhwc (filter resident in LDS) against the oracle's convolution in float64 and

@@ -19,6 +19,8 @@ def main():
     ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'conv_tuned.json'))
     ap.add_argument('--fresh', action='store_true', help='ignore the shipped table')
     ap.add_argument('--drop', default='', help='time again the shapes whose table key contains this text')
+    ap.add_argument('--dtypes', default='bfloat16,float32,float32x3,mixed',
+                    help='compute modes whose layer shapes are tuned')
     args = ap.parse_args()
     from google.protobuf import text_format
     from protos import pipeline_pb2
@@ -35,7 +37,10 @@ def main():
             del plan.CompiledGraph._TUNE_CACHE[key]
     jobs = []
     for name, (cfg_file, in_shape, pad_shape, batches) in CASES.items():
-        for dtype, edges in (('bfloat16', (16, 32)), ('float32', (32, 16)), ('float32x3', (16, 32))):
+        for dtype, edges in (('bfloat16', (16, 32)), ('float32', (32, 16)), ('float32x3', (16, 32)),
+                             ('mixed', (16,))):
+            if dtype not in args.dtypes.split(','):
+                continue
             for b in batches:
                 if dtype == 'float32' and name not in ('icnet10',):      # float32x3: every model
                     continue
