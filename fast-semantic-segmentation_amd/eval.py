@@ -43,9 +43,11 @@ def main(argv=None):
     ap.add_argument('--image_summaries', action='store_true')
     ap.add_argument('--verbose', action='store_true')
     ap.add_argument('--limit_gpu_mem', action='store_true')
-    ap.add_argument('--dtype', default='float32x3', choices=['bfloat16', 'float32', 'float32x3'],
-                    help='float32x3 (default): float32 tensors, products as three bf16 MFMAs - the results of a '
-                         'float32 framework; bfloat16: 3x the throughput, labels differ on 0.1 - 2 %% of the pixels')
+    ap.add_argument('--dtype', default='mixed', choices=['mixed', 'float32x3', 'bfloat16', 'float32'],
+                    help='mixed (default): float32 tensors with products as three bf16 MFMAs, the 3x3 convolutions of the '
+                         'bottleneck units and the full-resolution branch in half precision - meets the float32 tolerances '
+                         '(logits 1e-3, labels 99.9 %%); float32x3: the same without half precision, the results of a float32 '
+                         'framework at 2/3 of the speed; bfloat16: twice the throughput, labels differ on 0.1 - 2 %% of the pixels')
     ap.add_argument('--batch_size', type=int, default=1)
     flags = ap.parse_args(argv)
 

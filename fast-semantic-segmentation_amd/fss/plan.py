@@ -112,7 +112,7 @@ class Val(object):
 
 class Step(object):
     __slots__ = ('kind', 'name', 'fn', 'args', 'flops', 'graph_flops', 'bytes', 'keep', 'stream', 'waits',
-                 'signal')
+                 'signal', 'mpp')
 
     def __init__(self, kind, name, fn, args, flops=0, nbytes=0, keep=None, graph_flops=None):
         self.kind, self.name, self.fn, self.args = kind, name, fn, args   # args[-1] is the stream
@@ -120,6 +120,7 @@ class Step(object):
         # FLOP of the graph nodes this launch stands for, as the graph is written (differs from
         # `flops`, the FLOP executed, where a rewrite lowered the operation count)
         self.graph_flops = flops if graph_flops is None else graph_flops
+        self.mpp = 1            # MFMA instructions issued per product (3: split-bf16 arithmetic)
         self.stream = 0         # 0: the plan's stream, 1: the side stream
         self.waits = []         # events its stream waits for before the launch
         self.signal = None      # event recorded on its stream after the launch
@@ -351,8 +352,10 @@ class CompiledGraph(object):
             return None
         return ln.consumers[0]
 
-    def _emit(self, kind, name, fname, args, flops=0, nbytes=0, keep=None, graph_flops=None):
+    def _emit(self, kind, name, fname, args, flops=0, nbytes=0, keep=None, graph_flops=None, mpp=1):
         st = Step(kind, name, getattr(lib, fname), args, flops, nbytes, keep, graph_flops)
+        d = keep[0] if isinstance(keep, tuple) and keep else keep
+        st.mpp = 3 if isinstance(d, _lib.ConvDesc) and d.in_dtype == _lib.F32_BF16X3 else mpp
         self.steps.append(st)
         self.step_fname.append(fname)
 
@@ -514,7 +517,7 @@ class CompiledGraph(object):
                     _lib.ACT_CODES[a['activation']], code, out.ld, self.sh),
                    flops=2 * n * ho * wo * cout * kh * kw * 3,
                    nbytes=n * (hr // sub) * (wr // sub) * 3 + n * ho * wo * cout * _ESZ[self.dt],
-                   keep=(mean, sc))
+                   keep=(mean, sc), mpp=3 if code == _lib.F32_BF16X3 else 1)
 
     def _stem2_partner(self, ln):
         """(the convolution that consumes stem conv `ln`, the 16-bit type) when both can run as
@@ -1722,6 +1725,7 @@ class CompiledGraph(object):
         for e in evs:
             _lib.call('fss_event_destroy', e)
         return [dict(kind=s.kind, name=s.name, ms=best[k], mean_ms=total[k] / repeats, flops=s.flops, graph_flops=s.graph_flops, bytes=s.bytes,
+                     mfma_per_product=s.mpp, fname=self.step_fname[k],
                      config=((s.keep[0] if isinstance(s.keep, tuple) else s.keep).config
                              + (1000 * s.args[6] if self.step_fname[k] == 'fss_conv2d_splitk_nhwc' else 0)
                              if s.kind == 'conv' else None))

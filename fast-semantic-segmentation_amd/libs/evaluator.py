@@ -87,7 +87,7 @@ def eval_segmentation_model_once(checkpoint_path, create_model_fn, create_input_
 def eval_segmentation_model(create_model_fn, create_input_fn, input_dimensions, eval_config,
                             train_dir, eval_dir, cropped_evaluation=False,
                             evaluate_single_checkpoint=None, image_summaries=False,
-                            verbose=False, sess_config=None, weights=None, dtype='float32x3',
+                            verbose=False, sess_config=None, weights=None, dtype='mixed',
                             batch_size=1, return_confusion=False):
     import torch
     import torch.distributed as dist

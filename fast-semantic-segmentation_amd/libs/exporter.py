@@ -55,7 +55,7 @@ class Session(object):
     """Compiles `outputs` for the GPU with the given weights; `run` is the
     counterpart of `sess.run(outputs, feed_dict={placeholder: image})`."""
 
-    def __init__(self, outputs, placeholder, weights, dtype='float32x3', graph=None, **plan_kwargs):
+    def __init__(self, outputs, placeholder, weights, dtype='mixed', graph=None, **plan_kwargs):
         from fss import plan      # needs the GPU library; imported on first use
         self._outputs = outputs if isinstance(outputs, (list, tuple)) else [outputs]
         self._single = not isinstance(outputs, (list, tuple))

@@ -158,3 +158,22 @@ print('RCCL_OK')
                PYTHONPATH=os.pathsep.join([ROOT, PKG, os.environ.get('PYTHONPATH', '')]))
     out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'RCCL_OK' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_bench_starts_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no launcher around it): the script starts two fresh ranks
+    before any GPU call and relays rank 0's line.  Both ranks compute on this box's one GPU and
+    exchange the confusion matrix over gloo; an 8-GPU node runs the same code over RCCL."""
+    env = dict(os.environ, FSS_BENCH_BACKEND='gloo', FSS_BENCH_DEVICE='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--batch', '2',
+                          '--steps', '2', '--warmup', '1', '--quick'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['scaling'] == 'weak'
+    assert d['value'] > 0 and d['config']['frames_per_step_per_gpu'] == 2
+    assert d['roofline']['frac'] > 0 and d['roofline']['launches_per_step'] > 0

@@ -11,7 +11,7 @@ for grp in \
  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
  "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_WR SQ_LEVEL_WAVES SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA" ; do
   i=$((i+1))
-  timeout -s KILL 170 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -o p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-conformant --no-host-fed --no-latency > $OUT/g$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/g$i.log; exit 1; }
+  timeout -s KILL 170 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -o p -- python3 bench.py --steps 1 --warmup 1 --quick > $OUT/g$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/g$i.log; exit 1; }
   echo "pass $i done"
 done
 python3 - $OUT <<'PY'

@@ -1,18 +1,19 @@
 #!/bin/bash
 # Collect the judged evidence for one tag on a GPU box:
-#   tools/profile_round.sh r2_a            (run from the repo root via gpurun)
+#   tools/profile_round.sh r3_a [mixed|float32x3|bfloat16]     (run from the repo root via gpurun)
 # Writes gpurun_out/<tag>_*: bench JSON + layer table, rocprofv3 kernel stats of the shipped
 # (two-stream) graph and of the single-stream graph, the two TCC passes (FETCH_SIZE,
 # WRITE_SIZE) the conv traffic figure comes from, and SQ / TCP / TD counter passes whose
 # per-layer summary (MFMA pipe busy share, stalls) is <tag>_conv_pmc.txt.
 # Every counter pass is a run of its own (no trace options beside --pmc).
 set -o pipefail
-TAG=${1:-r2}
+TAG=${1:-r3}
+DTYPE=${2:-mixed}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-QUICK="--no-cpu-baseline --no-latency --no-conformant --no-host-fed"
-FSS_BENCH_LAYERS=$OUT/${TAG}_layers.txt timeout -k 10 400 python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+QUICK="--quick --dtype $DTYPE"
+FSS_BENCH_LAYERS=$OUT/${TAG}_layers.txt timeout -k 10 400 python3 bench.py --dtype $DTYPE --no-configs --no-throughput-mode --no-float32x3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 bench.py --steps 5 --warmup 2 $QUICK > $OUT/${TAG}_trace.log 2>&1 || exit 2
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace1 -o t -- python3 bench.py --steps 5 --warmup 2 --streams 1 $QUICK > $OUT/${TAG}_trace1.log 2>&1 || exit 2
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- python3 bench.py --steps 1 --warmup 0 $QUICK > $OUT/${TAG}_pmc_fetch.log 2>&1 || exit 3

@@ -55,9 +55,9 @@ def main():
         '# tcp_stall = TCP_PENDING_STALL_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs); td_busy = TD_TD_BUSY / (GRBM_GUI_ACTIVE / 8 * 256 CUs)',
         '# mfma_issue = SQ_INSTS_MFMA * (16 cycles per v_mfma_*_16x16x32, 32 per 32x32x16) / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)',
         '%-62s %8s %8s %8s %6s %10s %8s %9s %8s %s' % ('layer', 'ms', 'TFLOP/s', 'GB/s', 'mfma', 'mfma_issue', 'lds_wait', 'tcp_stall', 'td_busy', 'config')]
-    mfma_cycles = 32.0 if 'f32' in bench['dtype'] and 'x3' not in bench['dtype'] else 16.0
-    if os.environ.get('FSS_MFMA_EDGE') == '32' or 'bf16x3' in bench['dtype']:
-        mfma_cycles = 32.0
+    # 16 cycles per v_mfma_*_16x16x32 (bf16 / f16; the split-bf16 launches issue three per product),
+    # 32 per 32x32 shape (the exact float32 mode, or FSS_MFMA_EDGE=32)
+    mfma_cycles = 32.0 if bench['config'].get('compute_mode') == 'float32' or os.environ.get('FSS_MFMA_EDGE') == '32' else 16.0
     cus = 256.0 / 8.0          # GRBM_GUI_ACTIVE is summed over the 8 XCDs
 
     def ratio(a, b, k, scale=1.0):

@@ -36,7 +36,7 @@ def main():
     total = (2.0 * fetch + write) * 1024.0
     d = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py, '
                    'last eager profiling pass',
-         'dtype': 'bfloat16' if bench['dtype'] == 'bf16' else 'float32',
+         'dtype': bench['config'].get('compute_mode') or ('bfloat16' if bench['dtype'] == 'bf16' else 'float32'),
          'frames_per_step': batch, 'conv_launches_per_step': n,
          'conv_fetch_size_kb_raw': fetch, 'conv_write_size_kb_raw': write,
          'fetch_correction': 'x2 (gfx950 FETCH_SIZE counts 128-B requests as 64 B)',
