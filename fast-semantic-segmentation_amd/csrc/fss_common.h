@@ -108,6 +108,38 @@ __device__ __forceinline__ fss_f32x4 mfma_16x16x32(const uint4& a, const uint4& 
                                                    __builtin_bit_cast(fss_bf16x8, b), acc, 0, 0, 0);
 }
 
+// Split-bfloat16 tensors (dtype FSS_F32_BF16X3): one 4-byte slot per element, like float, but
+// every 8 consecutive channels (32 bytes) hold their 8 bf16 high parts followed by their 8 bf16
+// remainders: v = hi + lo with hi = bf16(v), lo = bf16(v - hi), about 16 significant bits.  The
+// halves of such a group are ready-made operands of the bf16 matrix cores (a_hi*b_hi + a_hi*b_lo
+// + a_lo*b_hi), so a convolution reading them splits nothing in its main loop; the producer
+// splits each value once when it stores it.  The tag type stands for one slot.
+struct f32s_t { float slot; };
+
+// 8 floats -> their bf16 high parts and bf16 remainders, packed 8 per uint4 in element order.
+// Round to nearest even, so that the remainders (and the dropped lo*lo terms) have no
+// systematic sign: truncation would bias every product the same way.
+__device__ __forceinline__ void split8(const float (&f)[8], uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = f[2 * i], b = f[2 * i + 1];
+    h[i] = pack_bf16x2(a, b);
+    l[i] = pack_bf16x2(a - __uint_as_float(h[i] << 16), b - __uint_as_float(h[i] & 0xffff0000u));
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// ... and back: the 8 values of a group from its two 16-byte halves
+__device__ __forceinline__ void join8(const uint4& hi, const uint4& lo, float (&f)[8]) {
+  const unsigned h[4] = {hi.x, hi.y, hi.z, hi.w}, l[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(h[i] << 16) + __uint_as_float(l[i] << 16);
+    f[2 * i + 1] = __uint_as_float(h[i] & 0xffff0000u) + __uint_as_float(l[i] & 0xffff0000u);
+  }
+}
+
 // 16-byte store that does not keep the line in the caches (outputs far larger than L2 that
 // the same kernel never reads back)
 typedef unsigned fss_u32x4 __attribute__((ext_vector_type(4)));
@@ -136,7 +168,28 @@ template <> struct ElemTraits<f16_t> {
   }
 };
 
-// A 16-byte chunk of T viewed as floats.
+// One element of a split-bfloat16 tensor by its slot address (slow paths only): the group
+// starts at the slot address rounded down to 32 bytes, the halves are 16 bytes apart.
+template <> struct ElemTraits<f32s_t> {
+  static constexpr int kPerChunk = 8;
+  static __device__ __forceinline__ float load(const f32s_t* p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const unsigned short* g = reinterpret_cast<const unsigned short*>(a & ~(uintptr_t)31);
+    const int i = (int)((a >> 2) & 7);
+    return bf16_to_f32(g[i]) + bf16_to_f32(g[8 + i]);
+  }
+  static __device__ __forceinline__ void store(f32s_t* p, float v) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    unsigned short* g = reinterpret_cast<unsigned short*>(a & ~(uintptr_t)31);
+    const int i = (int)((a >> 2) & 7);
+    const bf16_t h = f32_to_bf16(v);
+    g[i] = h;
+    g[8 + i] = f32_to_bf16(v - bf16_to_f32(h));
+  }
+};
+
+// A channel chunk of T viewed as floats: 16 bytes (4 floats, 8 bf16 / half values), or the
+// 32-byte group of 8 channels of a split-bfloat16 tensor.
 template <typename T> struct Chunk;
 template <> struct Chunk<float> {
   static constexpr int N = 4;
@@ -175,6 +228,43 @@ template <> struct Chunk<bf16_t> {
                pack_bf16x2(v[6], v[7]));
   }
 };
+
+template <> struct Chunk<f32s_t> {
+  static constexpr int N = 8;
+  float v[8];
+  __device__ __forceinline__ void load(const f32s_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    join8(q[0], q[1], v);
+  }
+  __device__ __forceinline__ void store(f32s_t* p) const {
+    uint4 hi, lo;
+    split8(v, hi, lo);
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = hi;
+    q[1] = lo;
+  }
+  __device__ __forceinline__ void store_nt(f32s_t* p) const {
+    uint4 hi, lo;
+    split8(v, hi, lo);
+    store16_nt(p, hi.x, hi.y, hi.z, hi.w);
+    store16_nt(p + 4, lo.x, lo.y, lo.z, lo.w);
+  }
+};
+template <> struct Chunk<f16_t> {
+  static constexpr int N = 8;
+  float v[8];
+  __device__ __forceinline__ void load(const f16_t* p) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = Half16<f16_t>::lo(w[i]);
+      v[2 * i + 1] = Half16<f16_t>::hi(w[i]);
+    }
+  }
+};
+// bytes of a channel chunk of T (what the copy kernels move per thread)
+template <typename T> struct ChunkBytes { static constexpr int value = Chunk<T>::N * (int)sizeof(T); };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
   if (act == FSS_ACT_RELU) return fmaxf(v, 0.f);

@@ -47,7 +47,7 @@ using namespace fss;
 extern "C" int fss_conv_pack_dims(int cin, int kh, int kw, int cout, int dtype, int* k_pad,
                                   int* cout_pad) {
   FSS_REQUIRE(k_pad && cout_pad, "null argument");
-  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F16, "bad dtype");
+  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F16 || dtype == FSS_F32_BF16X3, "bad dtype");
   FSS_REQUIRE(cin > 0 && kh > 0 && kw > 0 && cout > 0, "bad shape");
   const int k = cin * kh * kw;
   *k_pad = (k + 63) / 64 * 64;          // a multiple of every K tile in use
@@ -86,16 +86,26 @@ static int conv_setup(const fss_conv_desc* d, const void* x, const void* x2, int
   FSS_REQUIRE(d && x && w_packed && y, "null argument");
   FSS_REQUIRE(d->in_dtype == FSS_F32 || d->in_dtype == FSS_BF16 || d->in_dtype == FSS_F32_BF16X3 ||
                   d->in_dtype == FSS_F16, "bad in_dtype");
-  FSS_REQUIRE(d->out_dtype == FSS_F32 || d->out_dtype == FSS_BF16 || d->out_dtype == FSS_F16, "bad out_dtype");
+  FSS_REQUIRE(d->out_dtype == FSS_F32 || d->out_dtype == FSS_BF16 || d->out_dtype == FSS_F16 ||
+                  d->out_dtype == FSS_F32_BF16X3, "bad out_dtype");
   FSS_REQUIRE(!(d->in_dtype != FSS_BF16 && d->out_dtype == FSS_BF16),
               "bf16 output needs bf16 input");
-  FSS_REQUIRE(!(d->out_dtype == FSS_F16 && d->in_dtype != FSS_F16 && d->in_dtype != FSS_F32_BF16X3),
-              "f16 output needs f16 or FSS_F32_BF16X3 input");
+  FSS_REQUIRE(!((d->out_dtype == FSS_F16 || d->out_dtype == FSS_F32_BF16X3) && d->in_dtype != FSS_F16 &&
+                d->in_dtype != FSS_F32_BF16X3),
+              "f16 and split-bf16 outputs need f16 or FSS_F32_BF16X3 input");
   const bool half_in = d->in_dtype == FSS_BF16 || d->in_dtype == FSS_F16;
-  const int epc = half_in ? 8 : 4;
+  // channels per addressable group of the input (16 bytes; 32 for split-bf16 tensors)
+  const int epc = half_in || d->in_dtype == FSS_F32_BF16X3 ? 8 : 4;
   const int esz = half_in ? 2 : 4;
+  if (d->out_dtype == FSS_F32_BF16X3)
+    FSS_REQUIRE(d->cout % 8 == 0 && d->y_ld % 8 == 0 && ((uintptr_t)y & 31) == 0,
+                "split-bf16 output: cout and y_ld in multiples of 8, y 32-byte aligned");
+  if (residual != nullptr && (d->in_dtype == FSS_F32_BF16X3 || (d->in_dtype == FSS_F16 && d->out_dtype == FSS_F32_BF16X3)))
+    FSS_REQUIRE(d->res_ld % 8 == 0 && ((uintptr_t)residual & 31) == 0,
+                "split-bf16 residual: res_ld a multiple of 8, 32-byte aligned");
   FSS_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "bad shape");
-  FSS_REQUIRE(d->cin % epc == 0, "cin must be a multiple of 16 bytes of elements");
+  FSS_REQUIRE(d->cin % epc == 0, "cin must be a multiple of 16 bytes of elements (split-bf16: of 8)");
+  if (d->in_dtype == FSS_F32_BF16X3) FSS_REQUIRE(((uintptr_t)x & 31) == 0, "split-bf16 input must be 32-byte aligned");
   FSS_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dilation > 0, "bad filter");
   FSS_REQUIRE(d->ho > 0 && d->wo > 0, "bad output size");
   FSS_REQUIRE(d->pad_top >= 0 && d->pad_left >= 0, "negative padding");
@@ -145,6 +155,7 @@ extern "C" int fss_conv2d_dual_nhwc(const fss_conv_desc* d, const void* x, const
   if (d->in_dtype == FSS_F16 || d->out_dtype == FSS_F16)
     return dispatch_conv_half(a, d->in_dtype, d->out_dtype, d->config, s);
   if (d->in_dtype == FSS_F32) return dispatch_conv<float, float>(a, d->config, s);
+  if (d->in_dtype == FSS_F32_BF16X3 && d->out_dtype == FSS_F32_BF16X3) return dispatch_conv<f32s_t, f32s_t>(a, d->config, s);
   if (d->in_dtype == FSS_F32_BF16X3) return dispatch_conv<f32s_t, float>(a, d->config, s);
   if (d->out_dtype == FSS_BF16) return dispatch_conv<bf16_t, bf16_t>(a, d->config, s);
   return dispatch_conv<bf16_t, float>(a, d->config, s);
@@ -159,6 +170,8 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
   FSS_REQUIRE(d->in_dtype == FSS_BF16 || d->in_dtype == FSS_F32_BF16X3,
               "the classifier-head form takes bf16 activations, or float ones in the FSS_F32_BF16X3 mode");
   const unsigned long long esz = d->in_dtype == FSS_BF16 ? 2ull : 4ull;
+  if (d->in_dtype == FSS_F32_BF16X3 && residual != nullptr)
+    FSS_REQUIRE(((uintptr_t)residual & 31) == 0, "split-bf16 residual must be 32-byte aligned");
   FSS_REQUIRE(cout_head > 0 && cout_head <= kHeadMax, "cout_head out of range");
   FSS_REQUIRE(y_head_ld >= cout_head, "y_head_ld < cout_head");
   FSS_REQUIRE(d->cout % 32 == 0 && d->cout <= 256, "cout must be a multiple of 32, at most 256");
@@ -243,21 +256,21 @@ extern "C" int fss_conv2d_splitk_nhwc(const fss_conv_desc* d, const void* x, con
   if (rc) return rc;
   const long long threads = (long long)a.M * (ld / 4);
   const unsigned blocks = (unsigned)((threads + 255) / 256);
-  if (d->in_dtype == FSS_BF16 && d->out_dtype == FSS_BF16)
-    hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, s, workspace, splits,
-                       a.M, ld, d->cout, bias, (const bf16_t*)residual, d->res_ld, (bf16_t*)y, d->y_ld, d->act);
-  else if (d->in_dtype == FSS_BF16)
-    hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, s, workspace, splits,
-                       a.M, ld, d->cout, bias, (const bf16_t*)residual, d->res_ld, (float*)y, d->y_ld, d->act);
-  else if (d->in_dtype == FSS_F16 && d->out_dtype == FSS_F16)
-    hipLaunchKernelGGL((splitk_reduce_kernel<f16_t, f16_t>), dim3(blocks), dim3(256), 0, s, workspace, splits,
-                       a.M, ld, d->cout, bias, (const f16_t*)residual, d->res_ld, (f16_t*)y, d->y_ld, d->act);
-  else if (d->out_dtype == FSS_F16)
-    hipLaunchKernelGGL((splitk_reduce_kernel<float, f16_t>), dim3(blocks), dim3(256), 0, s, workspace, splits,
-                       a.M, ld, d->cout, bias, (const float*)residual, d->res_ld, (f16_t*)y, d->y_ld, d->act);
-  else
-    hipLaunchKernelGGL((splitk_reduce_kernel<float, float>), dim3(blocks), dim3(256), 0, s, workspace, splits,
-                       a.M, ld, d->cout, bias, (const float*)residual, d->res_ld, (float*)y, d->y_ld, d->act);
+  // residual type: the input's; for half-precision input, the output's
+#define FSS_REDUCE(TR, TO)                                                                              \
+  hipLaunchKernelGGL((splitk_reduce_kernel<TR, TO>), dim3(blocks), dim3(256), 0, s, workspace, splits, a.M, \
+                     ld, d->cout, bias, (const TR*)residual, d->res_ld, (TO*)y, d->y_ld, d->act)
+  const int in = d->in_dtype, out = d->out_dtype;
+  if (in == FSS_BF16 && out == FSS_BF16) FSS_REDUCE(bf16_t, bf16_t);
+  else if (in == FSS_BF16) FSS_REDUCE(bf16_t, float);
+  else if (in == FSS_F16 && out == FSS_F16) FSS_REDUCE(f16_t, f16_t);
+  else if (in == FSS_F16 && out == FSS_F32_BF16X3) FSS_REDUCE(f32s_t, f32s_t);
+  else if (in == FSS_F16) FSS_REDUCE(float, float);
+  else if (in == FSS_F32_BF16X3 && out == FSS_F16) FSS_REDUCE(f32s_t, f16_t);
+  else if (in == FSS_F32_BF16X3 && out == FSS_F32_BF16X3) FSS_REDUCE(f32s_t, f32s_t);
+  else if (in == FSS_F32_BF16X3) FSS_REDUCE(f32s_t, float);
+  else FSS_REDUCE(float, float);
+#undef FSS_REDUCE
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
     set_error(std::string("splitk_reduce launch: ") + hipGetErrorString(e));

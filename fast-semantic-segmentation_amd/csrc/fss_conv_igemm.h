@@ -24,35 +24,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 //            accumulator reg q holds C[4*g + q][r].
 // A float chunk is 4 k values, consumed by 4 f32 MFMAs with the same k permutation
 // on both operands.
-// Storage tag of the split-bfloat16 mode: tensors are float in memory and in LDS (everything
-// but the MFMA step is the float path), and each product a*b is formed on the bf16 matrix
-// pipe as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with a = a_hi + a_lo (a_hi = bf16(a),
-// a_lo = bf16(a - a_hi), the subtraction exact), which keeps about 16 mantissa bits per
-// operand: float-class results at three bf16 MFMAs per step instead of the 16x slower float
-// MFMAs.  Activations are split in registers; the weights arrive split by the caller (same
-// bytes as float: per 8 k values 8 bf16 high parts, then 8 bf16 remainders).
-struct f32s_t { float v; };
-template <> struct ElemTraits<f32s_t> {
-  static __device__ __forceinline__ float load(const f32s_t* p) { return p->v; }
-};
-
-// 8 floats (two 16-byte chunks) -> their bf16 high parts and bf16 remainders, packed 8 per uint4
-// in the element order (c0.x, c0.y, c0.z, c0.w, c1.x, ...) on both outputs.
-__device__ __forceinline__ void split8(const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) {
-  const unsigned f[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a = __uint_as_float(f[2 * i]), b = __uint_as_float(f[2 * i + 1]);
-    // round to nearest even, so that the remainders (and the dropped lo*lo terms) have no
-    // systematic sign: truncation would bias every product the same way
-    h[i] = pack_bf16x2(a, b);
-    l[i] = pack_bf16x2(a - __uint_as_float(h[i] << 16), b - __uint_as_float(h[i] & 0xffff0000u));
-  }
-  hi = make_uint4(h[0], h[1], h[2], h[3]);
-  lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-
+// Split-bfloat16 mode (tensors of f32s_t slots, see fss_common.h): each product a*b is formed on
+// the bf16 matrix pipe as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi, which keeps about 16 mantissa bits
+// per operand: float-class results at three bf16 MFMAs per step instead of the 16x slower float
+// MFMAs.  Activations and weights both arrive split (per 8 k values 8 bf16 high parts, then 8
+// bf16 remainders), so the main loop is the bf16 loop with twice the bytes per k and three
+// MFMAs per fragment pair; the epilogue splits each output value once.
 template <typename T, int FM> struct Mma;
 template <> struct Mma<bf16_t, 32> {
   typedef f32x16 acc_t;
@@ -390,7 +367,9 @@ conv_igemm_kernel(const ConvArgs a) {
   static_assert(WAVES_M * WAVES_N * SLABR * SROW * 4 <= NSTAGE * STAGE_BYTES,
                 "epilogue staging does not fit in the ring");
   static_assert(SLABR % FM == 0, "a staging slab must hold whole MFMA tiles");
-  constexpr int VW = 16 / (int)sizeof(TO);   // outputs per lane per pass: one 16-byte store
+  // outputs per lane per pass: one 16-byte store, or the two of a split-bfloat16 group
+  constexpr bool SPLIT_OUT = std::is_same<TO, f32s_t>::value;
+  constexpr int VW = SPLIT_OUT ? 8 : 16 / (int)sizeof(TO);
   constexpr int QPR = WTN / VW;              // lane pieces per staged row
   constexpr int PASSES = SLABR * QPR / 64;   // pieces per lane per slab
   static_assert(SLABR * QPR % 64 == 0, "slab must split evenly over the lanes");
@@ -416,19 +395,26 @@ conv_igemm_kernel(const ConvArgs a) {
     const char* pa = smem + slot * STAGE_BYTES + (wm * WTM + lrow) * BKB;
     const char* pb = smem + slot * STAGE_BYTES + BM * BKB + (wn * WTN + lrow) * BKB;
     if constexpr (MMA::PAIRED) {
-      // split mode: per MFMA step lane group lg owns the 8 consecutive k values of the chunk
-      // pair (2q, 2q + 1), q = LG * step + lg: 8 floats of A (split here), and the
-      // pre-split weights, whose rows hold per 8 k values their 8 bf16 high parts (chunk 2q)
-      // followed by their 8 bf16 remainders (chunk 2q + 1)
+      // split mode: per MFMA step a lane group owns the 8 consecutive k values of one chunk
+      // pair (2q, 2q + 1) of both operands: their 8 bf16 high parts (chunk 2q) and their 8 bf16
+      // remainders (chunk 2q + 1)
       static_assert(KSTEPS % 2 == 0, "split mode pairs the chunks of a tile row");
+      // Which chunk pair a lane group takes (the same on both operands, so any order is right).
+      // With four lane groups the order 0, 3, 1, 2 keeps the fragment reads free of bank
+      // conflicts: ds_read_b128 serves lane groups (0, 1) and (2, 3) together, eight rows of
+      // each, and the swizzle separates their 16-byte windows only when the chunk indices of the
+      // two groups agree, or are complementary, in their upper two bits - true for chunks
+      // (lg, lg + 1) of the bf16 loop, not for the even chunks (2 lg, 2 lg + 2) read here.
+      const int qg = LG == 4 ? ((lg & 1) ? 3 - (lg >> 1) : (lg >> 1)) : lg;
 #pragma unroll
       for (int s = 0; s < KSTEPS / 2; ++s) {
-        const int o0 = ((2 * (LG * s + lg)) ^ swz) * 16, o1 = ((2 * (LG * s + lg) + 1) ^ swz) * 16;
+        const int o0 = ((2 * (LG * s + qg)) ^ swz) * 16, o1 = ((2 * (LG * s + qg) + 1) ^ swz) * 16;
         uint4 ahi[MI], alo[MI], bhi[NI], blo[NI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-          split8(*reinterpret_cast<const uint4*>(pa + i * FM * BKB + o0),
-                 *reinterpret_cast<const uint4*>(pa + i * FM * BKB + o1), ahi[i], alo[i]);
+        for (int i = 0; i < MI; ++i) {
+          ahi[i] = *reinterpret_cast<const uint4*>(pa + i * FM * BKB + o0);
+          alo[i] = *reinterpret_cast<const uint4*>(pa + i * FM * BKB + o1);
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
           bhi[j] = *reinterpret_cast<const uint4*>(pb + j * FM * BKB + o0);
@@ -487,8 +473,7 @@ conv_igemm_kernel(const ConvArgs a) {
     };
     auto floats8 = [](const Raw8& r, float (&f)[8]) {
       if constexpr (SPLIT) {
-        f[0] = __uint_as_float(r.a.x); f[1] = __uint_as_float(r.a.y); f[2] = __uint_as_float(r.a.z); f[3] = __uint_as_float(r.a.w);
-        f[4] = __uint_as_float(r.b.x); f[5] = __uint_as_float(r.b.y); f[6] = __uint_as_float(r.b.z); f[7] = __uint_as_float(r.b.w);
+        join8(r.a, r.b, f);
       } else {
         f[0] = __uint_as_float(r.a.x << 16); f[1] = __uint_as_float(r.a.x & 0xffff0000u);
         f[2] = __uint_as_float(r.a.y << 16); f[3] = __uint_as_float(r.a.y & 0xffff0000u);
@@ -629,8 +614,8 @@ conv_igemm_kernel(const ConvArgs a) {
               for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.25f; d1[e] += r1[e] * 0.25f; }
             }
           } else {
-            // float sources: the addresses of the (up to) four sources first, then 4 channels
-            // (one 16-byte load per source) at a time, so that at most four loaded vectors are live
+            // split-bfloat16 sources (32 bytes per 8 channels): the addresses of the (up to) four
+            // sources first
             const unsigned zbase = (zo[i] & ~15u) + (unsigned)(32 * s) * ESZ;
             const unsigned zdr = (zo[i] & 1u) ? zrow : 0u, zdc = (zo[i] & 2u) ? zpix : 0u;
             const bool two = zeven[i] && !zborder[i];
@@ -667,21 +652,31 @@ conv_igemm_kernel(const ConvArgs a) {
                 src[nb] = base + off;
               }
             }
+            // split-bfloat16 sources: the high parts (first 16 bytes of the group) and the
+            // remainders (second 16 bytes) are summed over the sources one after the other, so
+            // that at most four loaded vectors are live; value = high part + remainder is linear
+            float r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            auto add8 = [&](const uint4& t) {
+              r8[0] += __uint_as_float(t.x << 16); r8[1] += __uint_as_float(t.x & 0xffff0000u);
+              r8[2] += __uint_as_float(t.y << 16); r8[3] += __uint_as_float(t.y & 0xffff0000u);
+              r8[4] += __uint_as_float(t.z << 16); r8[5] += __uint_as_float(t.z & 0xffff0000u);
+              r8[6] += __uint_as_float(t.w << 16); r8[7] += __uint_as_float(t.w & 0xffff0000u);
+            };
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-              f32x4& d = hh == 0 ? d0 : d1;
-              const float4 t0 = *reinterpret_cast<const float4*>(src[0] + 16 * hh);
-              const float4 t1 = *reinterpret_cast<const float4*>(src[1] + 16 * hh);
+              const uint4 t0 = *reinterpret_cast<const uint4*>(src[0] + 16 * hh);
+              const uint4 t1 = *reinterpret_cast<const uint4*>(src[1] + 16 * hh);
               if (two) {
-                d[0] += (t0.x + t1.x) * 0.5f; d[1] += (t0.y + t1.y) * 0.5f;
-                d[2] += (t0.z + t1.z) * 0.5f; d[3] += (t0.w + t1.w) * 0.5f;
+                add8(t0); add8(t1);
               } else {
-                const float4 t2 = *reinterpret_cast<const float4*>(src[2] + 16 * hh);
-                const float4 t3 = *reinterpret_cast<const float4*>(src[3] + 16 * hh);
-                d[0] += ((t0.x + t1.x) + (t2.x + t3.x)) * 0.25f; d[1] += ((t0.y + t1.y) + (t2.y + t3.y)) * 0.25f;
-                d[2] += ((t0.z + t1.z) + (t2.z + t3.z)) * 0.25f; d[3] += ((t0.w + t1.w) + (t2.w + t3.w)) * 0.25f;
+                const uint4 t2 = *reinterpret_cast<const uint4*>(src[2] + 16 * hh);
+                const uint4 t3 = *reinterpret_cast<const uint4*>(src[3] + 16 * hh);
+                add8(t0); add8(t1); add8(t2); add8(t3);
               }
             }
+            const float zsc = two ? 0.5f : 0.25f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d0[e] += r8[e] * zsc; d1[e] += r8[4 + e] * zsc; }
           }
         } else if (a.res != nullptr) {
           if constexpr (!SPLIT) {
@@ -709,9 +704,7 @@ conv_igemm_kernel(const ConvArgs a) {
                              cl(d1[0] + b1.x), cl(d1[1] + b1.y), cl(d1[2] + b1.z), cl(d1[3] + b1.w)};
         if constexpr (SPLIT) {
           uint4 fh, fl;
-          split8(make_uint4(__float_as_uint(v8[0]), __float_as_uint(v8[1]), __float_as_uint(v8[2]), __float_as_uint(v8[3])),
-                 make_uint4(__float_as_uint(v8[4]), __float_as_uint(v8[5]), __float_as_uint(v8[6]), __float_as_uint(v8[7])),
-                 fh, fl);
+          split8(v8, fh, fl);
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) MMA::run3(acc2[i][ct], wa[ct], wal[ct], fh, fl);
         } else {
@@ -831,7 +824,18 @@ conv_igemm_kernel(const ConvArgs a) {
         TO* dst = yg + (size_t)m * a.y_ld + n;
         if (vec_ok) {
           if (rg != nullptr) {
-            if constexpr (sizeof(TR) == 4) {
+            if constexpr (std::is_same<TR, f32s_t>::value) {
+              if constexpr (VW == 8) {
+                const uint4* rq = reinterpret_cast<const uint4*>(rg + (size_t)m * a.res_ld + n);
+                float r8[8];
+                join8(rq[0], rq[1], r8);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += r8[q];
+              } else {
+#pragma unroll
+                for (int q = 0; q < VW; ++q) v[q] += ElemTraits<TR>::load(rg + (size_t)m * a.res_ld + n + q);
+              }
+            } else if constexpr (sizeof(TR) == 4) {
 #pragma unroll
               for (int q = 0; q < VW; q += 4) {
                 const float4 r4 = *reinterpret_cast<const float4*>(rg + (size_t)m * a.res_ld + n + q);
@@ -849,7 +853,12 @@ conv_igemm_kernel(const ConvArgs a) {
           }
 #pragma unroll
           for (int e = 0; e < VW; ++e) v[e] = fminf(fmaxf(v[e], act_lo), act_hi);
-          if constexpr (sizeof(TO) == 4) {
+          if constexpr (SPLIT_OUT) {
+            uint4 hi, lo;
+            split8(v, hi, lo);
+            store16_nt(dst, hi.x, hi.y, hi.z, hi.w);
+            store16_nt(dst + 4, lo.x, lo.y, lo.z, lo.w);
+          } else if constexpr (sizeof(TO) == 4) {
             store16_nt(dst, __float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
           } else {
             typedef Half16<TO> HO;
@@ -1014,8 +1023,8 @@ static int dispatch_conv(ConvArgs& a, int config, hipStream_t stream) {
 }
 
 // The half-precision instantiations live in a translation unit of their own (fss_conv_f16.hip):
-// in_dtype FSS_F16 with out_dtype FSS_F16 / FSS_F32, or in_dtype FSS_F32_BF16X3 with out_dtype
-// FSS_F16.
+// in_dtype FSS_F16 with out_dtype FSS_F16 / FSS_F32_BF16X3 / FSS_F32, or in_dtype FSS_F32_BF16X3
+// with out_dtype FSS_F16.
 int dispatch_conv_half(ConvArgs& a, int in_dtype, int out_dtype, int config, hipStream_t stream);
 
 // Classifier-head form: the 16x16x32 configurations whose N tile holds every output channel

@@ -79,9 +79,11 @@ __global__ void subsample_kernel(const T* __restrict__ x, T* __restrict__ y, int
   const int ow = (int)(p % Wo); p /= Wo;
   const int oh = (int)(p % Ho);
   const int n = (int)(p / Ho);
-  const uint4 v = *reinterpret_cast<const uint4*>(
+  const uint4* src = reinterpret_cast<const uint4*>(
       x + (((size_t)n * H + (size_t)oh * stride) * W + (size_t)ow * stride) * C + ch * E);
-  *reinterpret_cast<uint4*>(y + idx * E) = v;
+  uint4* dst = reinterpret_cast<uint4*>(y + idx * E);
+#pragma unroll
+  for (int q = 0; q < ChunkBytes<T>::value / 16; ++q) dst[q] = src[q];
 }
 
 // ------------------------------------------------------------ avg pool (bins)
@@ -388,8 +390,10 @@ __global__ void copy_channels_kernel(const T* __restrict__ x, int x_ld, T* __res
   if (idx >= pixels * cc) return;
   const int ch = (int)(idx % cc);
   const size_t p = idx / cc;
-  *reinterpret_cast<uint4*>(y + p * y_ld + ch * E) =
-      *reinterpret_cast<const uint4*>(x + p * x_ld + ch * E);
+  const uint4* src = reinterpret_cast<const uint4*>(x + p * x_ld + ch * E);
+  uint4* dst = reinterpret_cast<uint4*>(y + p * y_ld + ch * E);
+#pragma unroll
+  for (int q = 0; q < ChunkBytes<T>::value / 16; ++q) dst[q] = src[q];
 }
 
 // ------------------------------------------------------- pyramid average pooling
@@ -982,11 +986,14 @@ __global__ void dwconv3x3_kernel(const T* __restrict__ x, const float* __restric
 
 using namespace fss;
 
-#define FSS_DTYPE_OK(dt) FSS_REQUIRE((dt) == FSS_F32 || (dt) == FSS_BF16, "bad dtype")
+// tensor types of the bandwidth kernels: float, bfloat16, split-bfloat16 (FSS_F32_BF16X3: 4-byte
+// slots, 8 channels = 32 bytes of 8 high parts + 8 remainders)
+#define FSS_DTYPE_OK(dt) FSS_REQUIRE((dt) == FSS_F32 || (dt) == FSS_BF16 || (dt) == FSS_F32_BF16X3, "bad dtype")
+static inline int chunk_of(int dt) { return dt == FSS_F32 ? 4 : 8; }   // channels per chunk
 #define FSS_CHUNK_OK(c, dt)                                                      \
-  FSS_REQUIRE((c) > 0 && (c) % ((dt) == FSS_F32 ? 4 : 8) == 0,                   \
+  FSS_REQUIRE((c) > 0 && (c) % chunk_of(dt) == 0,                   \
               "channel count must be a multiple of 16 bytes of elements")
-#define FSS_ALIGNED(p) FSS_REQUIRE(((uintptr_t)(p) & 15) == 0, "unaligned pointer")
+#define FSS_ALIGNED(p) FSS_REQUIRE(((uintptr_t)(p) & (dtype == FSS_F32_BF16X3 ? 31 : 15)) == 0, "unaligned pointer")
 
 extern "C" {
 
@@ -1001,11 +1008,14 @@ int fss_maxpool_nhwc(const void* x, void* y, int n, int h, int wd, int c, int k,
   FSS_REQUIRE(pad_top >= 0 && pad_left >= 0 && pad_top < k && pad_left < k, "bad padding");
   FSS_REQUIRE((long long)(ho - 1) * stride - pad_top < h && (long long)(wo - 1) * stride - pad_left < wd,
               "output size exceeds the input");
-  const size_t total = (size_t)n * ho * wo * (c / (dtype == FSS_F32 ? 4 : 8));
+  const size_t total = (size_t)n * ho * wo * (c / chunk_of(dtype));
   hipStream_t s = (hipStream_t)stream;
   if (dtype == FSS_F32)
     hipLaunchKernelGGL(maxpool_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const float*)x, (float*)y, n, h, wd, c, k, stride, pad_top, pad_left, ho, wo);
+  else if (dtype == FSS_F32_BF16X3)
+    hipLaunchKernelGGL(maxpool_kernel<f32s_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const f32s_t*)x, (f32s_t*)y, n, h, wd, c, k, stride, pad_top, pad_left, ho, wo);
   else
     hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const bf16_t*)x, (bf16_t*)y, n, h, wd, c, k, stride, pad_top, pad_left, ho, wo);
@@ -1022,11 +1032,14 @@ int fss_subsample_nhwc(const void* x, void* y, int n, int h, int wd, int c, int 
   FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0 && stride > 0, "bad shape");
   FSS_REQUIRE((long long)(ho - 1) * stride < h && (long long)(wo - 1) * stride < wd,
               "output size exceeds the input");
-  const size_t total = (size_t)n * ho * wo * (c / (dtype == FSS_F32 ? 4 : 8));
+  const size_t total = (size_t)n * ho * wo * (c / chunk_of(dtype));
   hipStream_t s = (hipStream_t)stream;
   if (dtype == FSS_F32)
     hipLaunchKernelGGL(subsample_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const float*)x, (float*)y, n, h, wd, c, stride, ho, wo);
+  else if (dtype == FSS_F32_BF16X3)
+    hipLaunchKernelGGL(subsample_kernel<f32s_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const f32s_t*)x, (f32s_t*)y, n, h, wd, c, stride, ho, wo);
   else
     hipLaunchKernelGGL(subsample_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const bf16_t*)x, (bf16_t*)y, n, h, wd, c, stride, ho, wo);
@@ -1043,12 +1056,15 @@ int fss_avgpool_bins_nhwc(const void* x, void* y, int n, int h, int wd, int c, i
   FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && kh > 0 && kw > 0 && bh > 0 && bw > 0, "bad shape");
   FSS_REQUIRE((long long)bh * kh <= h && (long long)bw * kw <= wd, "bins exceed the input");
   constexpr int TX = 16, TY = 16;
-  const int cc = c / (dtype == FSS_F32 ? 4 : 8);
+  const int cc = c / chunk_of(dtype);
   dim3 grid((unsigned)(n * bh * bw), (unsigned)ceil_div(cc, TX));
   hipStream_t s = (hipStream_t)stream;
   if (dtype == FSS_F32)
     hipLaunchKernelGGL((avgpool_bins_kernel<float, TX, TY>), grid, dim3(TX, TY), 0, s,
                        (const float*)x, (float*)y, h, wd, c, kh, kw, bh, bw);
+  else if (dtype == FSS_F32_BF16X3)
+    hipLaunchKernelGGL((avgpool_bins_kernel<f32s_t, TX, TY>), grid, dim3(TX, TY), 0, s,
+                       (const f32s_t*)x, (f32s_t*)y, h, wd, c, kh, kw, bh, bw);
   else
     hipLaunchKernelGGL((avgpool_bins_kernel<bf16_t, TX, TY>), grid, dim3(TX, TY), 0, s,
                        (const bf16_t*)x, (bf16_t*)y, h, wd, c, kh, kw, bh, bw);
@@ -1093,7 +1109,7 @@ static int pyramid_pool_launch(const void* x, void* const* y, const int* kh, con
     a.y[l] = y[l];
   }
   FSS_REQUIRE(workspace_bytes >= (size_t)n * h * a.total_cols * c * sizeof(float), too_small);
-  const int cc = c / (dtype == FSS_F32 ? 4 : 8);
+  const int cc = c / chunk_of(dtype);
   hipStream_t s = (hipStream_t)stream;
   const size_t t1 = (size_t)n * h * cc, t2 = (size_t)n * a.total_bins * cc;
   // small problems: cut the rows into pieces at every bin edge for more threads
@@ -1122,6 +1138,11 @@ static int pyramid_pool_launch(const void* x, void* const* y, const int* kh, con
                          (const float*)x, workspace, n, h, wd, c, a);
       hipLaunchKernelGGL(pyramid_piecebin_kernel<float>, dim3(grid_for(t2 * kPyrRS)), dim3(kBlock), 0, s,
                          workspace, n, h, c, a);
+    } else if (dtype == FSS_F32_BF16X3) {
+      hipLaunchKernelGGL(pyramid_piecesum_kernel<f32s_t>, dim3(grid_for(tp)), dim3(kBlock), 0, s,
+                         (const f32s_t*)x, workspace, n, h, wd, c, a);
+      hipLaunchKernelGGL(pyramid_piecebin_kernel<f32s_t>, dim3(grid_for(t2 * kPyrRS)), dim3(kBlock), 0, s,
+                         workspace, n, h, c, a);
     } else {
       hipLaunchKernelGGL(pyramid_piecesum_kernel<bf16_t>, dim3(grid_for(tp)), dim3(kBlock), 0, s,
                          (const bf16_t*)x, workspace, n, h, wd, c, a);
@@ -1135,6 +1156,11 @@ static int pyramid_pool_launch(const void* x, void* const* y, const int* kh, con
     hipLaunchKernelGGL(pyramid_rowsum_kernel<float>, dim3(grid_for(t1)), dim3(kBlock), 0, s,
                        (const float*)x, workspace, n, h, wd, c, a);
     hipLaunchKernelGGL(pyramid_binavg_kernel<float>, dim3(grid_for(t2)), dim3(kBlock), 0, s,
+                       workspace, n, h, c, a);
+  } else if (dtype == FSS_F32_BF16X3) {
+    hipLaunchKernelGGL(pyramid_rowsum_kernel<f32s_t>, dim3(grid_for(t1)), dim3(kBlock), 0, s,
+                       (const f32s_t*)x, workspace, n, h, wd, c, a);
+    hipLaunchKernelGGL(pyramid_binavg_kernel<f32s_t>, dim3(grid_for(t2)), dim3(kBlock), 0, s,
                        workspace, n, h, c, a);
   } else {
     hipLaunchKernelGGL(pyramid_rowsum_kernel<bf16_t>, dim3(grid_for(t1)), dim3(kBlock), 0, s,
@@ -1205,15 +1231,19 @@ int fss_resize_bilinear_nhwc(const void* x, void* y, int n, int h, int wd, int c
   FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && c > 0 && ho > 0 && wo > 0, "bad shape");
   FSS_REQUIRE(y_ld >= c, "y_ld < c");
   const float sh = resize_scale(h, ho, align_corners), sw = resize_scale(wd, wo, align_corners);
-  const int e = dtype == FSS_F32 ? 4 : 8;
-  const bool vec = (c % e == 0) && (y_ld % e == 0) && (((uintptr_t)x & 15) == 0) &&
-                   (((uintptr_t)y & 15) == 0);
+  const int e = chunk_of(dtype);
+  const unsigned amask = dtype == FSS_F32_BF16X3 ? 31u : 15u;
+  const bool vec = (c % e == 0) && (y_ld % e == 0) && (((uintptr_t)x & amask) == 0) &&
+                   (((uintptr_t)y & amask) == 0);
+  FSS_REQUIRE(vec || dtype != FSS_F32_BF16X3,
+              "split-bf16 tensors: 32-byte aligned, channels and pixel stride in multiples of 8");
   hipStream_t s = (hipStream_t)stream;
   const size_t total = (size_t)n * ho * wo * (vec ? c / e : c);
 #define FSS_RESIZE(T, V)                                                                        \
   hipLaunchKernelGGL((resize_bilinear_kernel<T, V>), dim3(grid_for(total)), dim3(kBlock), 0, s, \
                      (const T*)x, (T*)y, n, h, wd, c, ho, wo, y_ld, sh, sw)
   if (dtype == FSS_F32) { if (vec) FSS_RESIZE(float, true); else FSS_RESIZE(float, false); }
+  else if (dtype == FSS_F32_BF16X3) { if (vec) FSS_RESIZE(f32s_t, true); else FSS_RESIZE(f32s_t, false); }
   else { if (vec) FSS_RESIZE(bf16_t, true); else FSS_RESIZE(bf16_t, false); }
 #undef FSS_RESIZE
   FSS_LAUNCH_CHECK();
@@ -1239,7 +1269,7 @@ int fss_pyramid_add_nhwc(const void* x, const void* const* p, const int* bh, con
     a.sh[l] = resize_scale(bh[l], h, 1);
     a.sw[l] = resize_scale(bw[l], wd, 1);
   }
-  const int cc = c / (dtype == FSS_F32 ? 4 : 8);
+  const int cc = c / chunk_of(dtype);
   const long long blocks = (long long)n * h * ((wd + kPyrPix - 1) / kPyrPix);
   FSS_REQUIRE(blocks < 0x7fffffffLL, "too many pixels");
   const int threads = cc >= 256 ? 256 : (cc >= 128 ? 128 : 64);
@@ -1247,6 +1277,9 @@ int fss_pyramid_add_nhwc(const void* x, const void* const* p, const int* bh, con
   if (dtype == FSS_F32)
     hipLaunchKernelGGL(pyramid_add_kernel<float>, dim3((unsigned)blocks), dim3(threads), 0, s,
                        (const float*)x, (float*)y, a, n, h, wd, c);
+  else if (dtype == FSS_F32_BF16X3)
+    hipLaunchKernelGGL(pyramid_add_kernel<f32s_t>, dim3((unsigned)blocks), dim3(threads), 0, s,
+                       (const f32s_t*)x, (f32s_t*)y, a, n, h, wd, c);
   else
     hipLaunchKernelGGL(pyramid_add_kernel<bf16_t>, dim3((unsigned)blocks), dim3(threads), 0, s,
                        (const bf16_t*)x, (bf16_t*)y, a, n, h, wd, c);
@@ -1258,7 +1291,7 @@ int fss_add_act(const void* a, const void* b, void* y, size_t count, int act, in
                 void* stream) {
   FSS_REQUIRE(a && b && y, "null argument");
   FSS_DTYPE_OK(dtype);
-  const int e = dtype == FSS_F32 ? 4 : 8;
+  const int e = chunk_of(dtype);
   FSS_REQUIRE(count > 0 && count % e == 0, "count must be a multiple of 16 bytes of elements");
   FSS_ALIGNED(a); FSS_ALIGNED(b); FSS_ALIGNED(y);
   const size_t chunks = count / e;
@@ -1266,6 +1299,9 @@ int fss_add_act(const void* a, const void* b, void* y, size_t count, int act, in
   if (dtype == FSS_F32)
     hipLaunchKernelGGL(add_act_kernel<float>, dim3(grid_for(chunks)), dim3(kBlock), 0, s,
                        (const float*)a, (const float*)b, (float*)y, chunks, act);
+  else if (dtype == FSS_F32_BF16X3)
+    hipLaunchKernelGGL(add_act_kernel<f32s_t>, dim3(grid_for(chunks)), dim3(kBlock), 0, s,
+                       (const f32s_t*)a, (const f32s_t*)b, (f32s_t*)y, chunks, act);
   else
     hipLaunchKernelGGL(add_act_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(kBlock), 0, s,
                        (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, chunks, act);
@@ -1278,7 +1314,7 @@ int fss_copy_channels(const void* x, int x_ld, void* y, int y_ld, size_t pixels,
   FSS_REQUIRE(x && y, "null argument");
   FSS_DTYPE_OK(dtype);
   FSS_CHUNK_OK(c, dtype);
-  const int e = dtype == FSS_F32 ? 4 : 8;
+  const int e = chunk_of(dtype);
   FSS_REQUIRE(x_ld >= c && y_ld >= c && x_ld % e == 0 && y_ld % e == 0, "bad pixel stride");
   FSS_ALIGNED(x); FSS_ALIGNED(y);
   FSS_REQUIRE(pixels > 0, "bad shape");
@@ -1287,6 +1323,9 @@ int fss_copy_channels(const void* x, int x_ld, void* y, int y_ld, size_t pixels,
   if (dtype == FSS_F32)
     hipLaunchKernelGGL(copy_channels_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const float*)x, x_ld, (float*)y, y_ld, pixels, c);
+  else if (dtype == FSS_F32_BF16X3)
+    hipLaunchKernelGGL(copy_channels_kernel<f32s_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const f32s_t*)x, x_ld, (f32s_t*)y, y_ld, pixels, c);
   else
     hipLaunchKernelGGL(copy_channels_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const bf16_t*)x, x_ld, (bf16_t*)y, y_ld, pixels, c);
@@ -1307,6 +1346,9 @@ int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho, i
   if (dtype == FSS_F32)
     hipLaunchKernelGGL(preprocess_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s, x,
                        (float*)y, n, h, wd, ho, wo, c_out, a);
+  else if (dtype == FSS_F32_BF16X3)
+    hipLaunchKernelGGL(preprocess_kernel<f32s_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, x,
+                       (f32s_t*)y, n, h, wd, ho, wo, c_out, a);
   else
     hipLaunchKernelGGL(preprocess_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s, x,
                        (bf16_t*)y, n, h, wd, ho, wo, c_out, a);
@@ -1321,12 +1363,15 @@ int fss_zoom2_border_gather(const void* x, void* tb, void* lr, void* cn, int n, 
   FSS_CHUNK_OK(c, dtype);
   FSS_ALIGNED(x); FSS_ALIGNED(tb); FSS_ALIGNED(lr); FSS_ALIGNED(cn);
   FSS_REQUIRE(n > 0 && h >= 4 && wd >= 4, "bad shape (h, w >= 4)");
-  const int cc = c / (dtype == FSS_F32 ? 4 : 8);
+  const int cc = c / chunk_of(dtype);
   const size_t total = ((size_t)2 * n * 3 * wd + (size_t)2 * n * h * 3 + (size_t)4 * n * 9) * cc;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == FSS_F32)
     hipLaunchKernelGGL(zoom2_border_gather_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const float*)x, (float*)tb, (float*)lr, (float*)cn, n, h, wd, c);
+  else if (dtype == FSS_F32_BF16X3)
+    hipLaunchKernelGGL(zoom2_border_gather_kernel<f32s_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const f32s_t*)x, (f32s_t*)tb, (f32s_t*)lr, (f32s_t*)cn, n, h, wd, c);
   else
     hipLaunchKernelGGL(zoom2_border_gather_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const bf16_t*)x, (bf16_t*)tb, (bf16_t*)lr, (bf16_t*)cn, n, h, wd, c);
@@ -1341,13 +1386,17 @@ int fss_zoom2_conv_commute(const void* y, const void* ytb, const void* ylr, cons
   FSS_CHUNK_OK(c, dtype);
   FSS_ALIGNED(y); FSS_ALIGNED(ytb); FSS_ALIGNED(ylr); FSS_ALIGNED(ycn); FSS_ALIGNED(r);
   FSS_REQUIRE(n > 0 && h >= 4 && wd >= 4, "bad shape (h, w >= 4)");
-  const int cc = c / (dtype == FSS_F32 ? 4 : 8);
+  const int cc = c / chunk_of(dtype);
   const size_t total = (size_t)n * (2 * h - 1) * (2 * wd - 1) * cc;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == FSS_F32)
     hipLaunchKernelGGL(zoom2_conv_commute_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const float*)y, (const float*)ytb, (const float*)ylr, (const float*)ycn,
                        (float*)r, n, h, wd, c);
+  else if (dtype == FSS_F32_BF16X3)
+    hipLaunchKernelGGL(zoom2_conv_commute_kernel<f32s_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const f32s_t*)y, (const f32s_t*)ytb, (const f32s_t*)ylr, (const f32s_t*)ycn,
+                       (f32s_t*)r, n, h, wd, c);
   else
     hipLaunchKernelGGL(zoom2_conv_commute_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const bf16_t*)y, (const bf16_t*)ytb, (const bf16_t*)ylr, (const bf16_t*)ycn,
@@ -1431,7 +1480,7 @@ int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y,
   // (small problems keep one thread per output chunk: more threads fill the chip better)
   constexpr int R = 4;
   const int runs = ceil_div(wo, R);
-  const size_t threads = (size_t)n * ho * runs * (c / (dtype == FSS_F32 ? 4 : 8));
+  const size_t threads = (size_t)n * ho * runs * (c / chunk_of(dtype));
   if (kh == 3 && kw == 3 && ((uintptr_t)w & 15) == 0 && threads >= 300000) {
 #define FSS_DW(T, ST, DL)                                                                            \
   hipLaunchKernelGGL((dwconv3x3_kernel<T, ST, DL, R>), dim3(grid_for(threads)), dim3(kBlock), 0, s,  \
@@ -1443,7 +1492,7 @@ int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y,
   else if (stride == 2 && dilation == 1) { FSS_DW(T, 2, 1); }          \
   else handled = false;
     bool handled = true;
-    if (dtype == FSS_F32) { FSS_DW_ANY(float) } else { FSS_DW_ANY(bf16_t) }
+    if (dtype == FSS_F32) { FSS_DW_ANY(float) } else if (dtype == FSS_F32_BF16X3) { FSS_DW_ANY(f32s_t) } else { FSS_DW_ANY(bf16_t) }
 #undef FSS_DW_ANY
 #undef FSS_DW
     if (handled) {
@@ -1451,10 +1500,14 @@ int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y,
       return 0;
     }
   }
-  const size_t total = (size_t)n * ho * wo * (c / (dtype == FSS_F32 ? 4 : 8));
+  const size_t total = (size_t)n * ho * wo * (c / chunk_of(dtype));
   if (dtype == FSS_F32)
     hipLaunchKernelGGL(dwconv_kernel<float>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const float*)x, w, bias, (float*)y, n, h, wd, c, kh, kw, stride, dilation,
+                       pad_top, pad_left, ho, wo, act);
+  else if (dtype == FSS_F32_BF16X3)
+    hipLaunchKernelGGL(dwconv_kernel<f32s_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const f32s_t*)x, w, bias, (f32s_t*)y, n, h, wd, c, kh, kw, stride, dilation,
                        pad_top, pad_left, ho, wo, act);
   else
     hipLaunchKernelGGL(dwconv_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,

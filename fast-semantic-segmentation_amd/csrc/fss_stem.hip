@@ -16,6 +16,7 @@
 // the packed weights are copied to LDS once per block, then the block walks
 // over 8x32-pixel output tiles.
 #include <algorithm>
+#include <type_traits>
 
 #include "fss_common.h"
 
@@ -61,7 +62,7 @@ template <> struct StemPix<float> {
 // SPLIT (T = bf16_t, TO = float): the float-quality form.  The preprocessed patch is kept as two
 // bf16 images (high parts, remainders), the weights arrive as two bf16 matrices (high parts
 // [cout_pad][k_pad], then remainders), and every MFMA step runs three times (lo*hi, hi*lo,
-// hi*hi) into the same float accumulators; the output is float.
+// hi*hi) into the same float accumulators; the output is a split-bfloat16 tensor (f32s_t).
 template <typename T, int NJ, int KS, typename TO = T, bool SPLIT = false>
 __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   constexpr int ES = (int)sizeof(T);
@@ -87,7 +88,8 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   // consecutive channels (one or two 16-byte stores per lane).  Float outputs: the natural order
   // 16*nj + 4*gg + q, so that one store instruction writes, per pixel, the 64 consecutive bytes of
   // the four lane groups instead of four 16-byte pieces 4*NJ*4 bytes apart.
-  constexpr bool NATURAL = sizeof(TO) == 4;
+  constexpr bool NATURAL = std::is_same<TO, float>::value;
+  constexpr bool SPLIT_OUT = std::is_same<TO, f32s_t>::value;
   auto chan_of = [](int nj, int gg, int q) { return NATURAL ? 16 * nj + 4 * gg + q : gg * (4 * NJ) + 4 * nj + q; };
   {
     const int cpr = a.K4pad * ES / 16;
@@ -112,7 +114,8 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   const float act_lo = a.act == FSS_ACT_NONE ? -INFINITY : 0.f;
   const float act_hi = a.act == FSS_ACT_RELU6 ? 6.f : INFINITY;
   // whole-lane vector stores need every lane's piece 16-byte aligned
-  const bool vec_ok = (a.y_ld * (int)sizeof(TO)) % 16 == 0 &&
+  // (split-bf16 output: a lane's 4*NJ consecutive channels must be whole groups of 8)
+  const bool vec_ok = (a.y_ld * (int)sizeof(TO)) % (SPLIT_OUT ? 32 : 16) == 0 && (!SPLIT_OUT || NJ % 2 == 0) &&
                       (NATURAL ? 16 * NJ <= a.Cout : g * (4 * NJ) + 4 * NJ <= a.Cout);
 
   // this wave's four 16-pixel groups: output rows 2*wave, 2*wave+1, columns 0-15 / 16-31.
@@ -375,7 +378,19 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
         for (int q = 0; q < 4; ++q)
           v[4 * nj + q] = __builtin_amdgcn_fmed3f(acc[mt][nj][q] + bias[nj][q], act_lo, act_hi);   // clamp
       if (vec_ok) {
-        if constexpr (sizeof(TO) == 4) {
+        if constexpr (SPLIT_OUT) {
+          if constexpr (NJ % 2 == 0) {
+#pragma unroll
+            for (int e = 0; e < NJ / 2; ++e) {
+              const float v8[8] = {v[8 * e], v[8 * e + 1], v[8 * e + 2], v[8 * e + 3],
+                                   v[8 * e + 4], v[8 * e + 5], v[8 * e + 6], v[8 * e + 7]};
+              uint4 hi, lo;
+              split8(v8, hi, lo);
+              store16_nt(dst + 8 * e, hi.x, hi.y, hi.z, hi.w);
+              store16_nt(dst + 8 * e + 4, lo.x, lo.y, lo.z, lo.w);
+            }
+          }
+        } else if constexpr (sizeof(TO) == 4) {
 #pragma unroll
           for (int nj = 0; nj < NJ; ++nj)
             store16_nt(dst + 16 * nj, __float_as_uint(v[4 * nj]), __float_as_uint(v[4 * nj + 1]),
@@ -473,6 +488,9 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
   FSS_REQUIRE(kh > 0 && kw > 0 && kh * kw <= 64, "filter must have at most 64 taps");
   FSS_REQUIRE((long long)hr * wr * 3 >= 4, "frame too small");
   FSS_REQUIRE(cout > 0 && cout <= 64, "cout must be in [1, 64]");
+  if (dtype == FSS_F32_BF16X3)
+    FSS_REQUIRE(cout % 8 == 0 && y_ld % 8 == 0 && ((uintptr_t)y & 31) == 0,
+                "split-bf16 output: cout and y_ld in multiples of 8, y 32-byte aligned");
   FSS_REQUIRE(stride > 0 && stride <= 4 && dilation > 0 && dilation <= 4, "bad stride / dilation");
   FSS_REQUIRE(pad_top >= 0 && pad_left >= 0, "negative padding");
   FSS_REQUIRE(act == FSS_ACT_NONE || act == FSS_ACT_RELU || act == FSS_ACT_RELU6, "bad act");
@@ -519,14 +537,14 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
   }
   if (dtype == FSS_F32) { FSS_STEM(float) }
   if (dtype == FSS_F32_BF16X3) {
-    if (nj == 4 && k_pad == 224) return launch_stem<bf16_t, 4, 7, float, true>(a, smem, s);
-    if (nj == 2 && k_pad == 64) return launch_stem<bf16_t, 2, 2, float, true>(a, smem, s);
-    if (nj == 4 && k_pad == 64) return launch_stem<bf16_t, 4, 2, float, true>(a, smem, s);
+    if (nj == 4 && k_pad == 224) return launch_stem<bf16_t, 4, 7, f32s_t, true>(a, smem, s);
+    if (nj == 2 && k_pad == 64) return launch_stem<bf16_t, 2, 2, f32s_t, true>(a, smem, s);
+    if (nj == 4 && k_pad == 64) return launch_stem<bf16_t, 4, 2, f32s_t, true>(a, smem, s);
     switch (nj) {
-      case 1: return launch_stem<bf16_t, 1, 0, float, true>(a, smem, s);
-      case 2: return launch_stem<bf16_t, 2, 0, float, true>(a, smem, s);
-      case 3: return launch_stem<bf16_t, 3, 0, float, true>(a, smem, s);
-      default: return launch_stem<bf16_t, 4, 0, float, true>(a, smem, s);
+      case 1: return launch_stem<bf16_t, 1, 0, f32s_t, true>(a, smem, s);
+      case 2: return launch_stem<bf16_t, 2, 0, f32s_t, true>(a, smem, s);
+      case 3: return launch_stem<bf16_t, 3, 0, f32s_t, true>(a, smem, s);
+      default: return launch_stem<bf16_t, 4, 0, f32s_t, true>(a, smem, s);
     }
   }
   // the two filters of the reference's networks: unrolled tap walk

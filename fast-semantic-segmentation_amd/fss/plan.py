@@ -33,10 +33,14 @@ import torch
 from fss import _lib
 from fss._lib import lib, check
 
-_TORCH_DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16, 'u8': torch.uint8}
-_CODE = {'f32': _lib.F32, 'bf16': _lib.BF16, 'f16': _lib.F16}
-_EPC = {'f32': 4, 'bf16': 8, 'f16': 8}
-_ESZ = {'f32': 4, 'bf16': 2, 'f16': 2, 'u8': 1}
+# storage types of a tensor.  'f32s': split-bfloat16 (FSS_F32_BF16X3) - one 4-byte slot per
+# element, every 8 channels stored as their 8 bf16 high parts followed by their 8 bf16 remainders;
+# what the float32x3 / mixed modes keep their activations in (the logits stay plain 'f32')
+_TORCH_DT = {'f32': torch.float32, 'f32s': torch.float32, 'bf16': torch.bfloat16, 'f16': torch.float16,
+             'u8': torch.uint8}
+_CODE = {'f32': _lib.F32, 'f32s': _lib.F32_BF16X3, 'bf16': _lib.BF16, 'f16': _lib.F16}
+_EPC = {'f32': 4, 'f32s': 8, 'bf16': 8, 'f16': 8}       # channels per addressable chunk
+_ESZ = {'f32': 4, 'f32s': 4, 'bf16': 2, 'f16': 2, 'u8': 1}
 
 # Convolutions (by the scope of their `weights` variable) that the 'mixed' mode computes in half
 # precision: the 3x3 convolution of every ResNet bottleneck unit (conv2,
@@ -62,6 +66,22 @@ def f32_to_f16_bits(a):
     """float32 ndarray -> uint16 ndarray of IEEE half bits (round to nearest even, saturating)."""
     a = np.clip(np.ascontiguousarray(a, dtype=np.float32), -65504.0, 65504.0)
     return a.astype(np.float16).view(np.uint16)
+
+
+def split_bf16_decode(raw):
+    """float32 ndarray holding split-bfloat16 groups along its last axis (a multiple of 8 slots:
+    8 bf16 high parts, then 8 bf16 remainders, per 8 elements) -> the float32 values."""
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    u = raw.view(np.uint16).reshape(raw.shape[:-1] + (raw.shape[-1] // 8, 2, 8)).astype(np.uint32) << 16
+    f = u.view(np.float32)
+    return (f[..., 0, :] + f[..., 1, :]).reshape(raw.shape)
+
+
+def split_bf16_encode(a):
+    """float32 ndarray (last axis a multiple of 8) -> float32-typed array holding its
+    split-bfloat16 form (same shape and bytes per element)."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return f32_split_bf16_rows(a.reshape(-1, a.shape[-1])).view(np.float32).reshape(a.shape)
 
 
 def f32_split_bf16_rows(wp):
@@ -163,7 +183,7 @@ class CompiledGraph(object):
         self.mixed = dtype == 'mixed'
         self.split = dtype in ('float32x3', 'f32x3', 'mixed')
         self.dt = {'float32': 'f32', 'bfloat16': 'bf16', 'f32': 'f32', 'bf16': 'bf16',
-                   'float32x3': 'f32', 'f32x3': 'f32', 'mixed': 'f32'}[dtype]
+                   'float32x3': 'f32s', 'f32x3': 'f32s', 'mixed': 'f32s'}[dtype]
         import re
         self.half_re = [re.compile(p) for p in (DEFAULT_HALF_SCOPES if half_scopes is None else half_scopes)]
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
@@ -291,7 +311,7 @@ class CompiledGraph(object):
 
     def _in_code(self, dt):
         """in_dtype code of a convolution whose input is stored as `dt`."""
-        return _lib.F32_BF16X3 if (dt == 'f32' and self.split) else _CODE[dt]
+        return _CODE[dt]
 
     def _pack(self, Wp, dt):
         """Packed float32 weight matrix -> device tensor in the form a convolution reading `dt`
@@ -300,7 +320,7 @@ class CompiledGraph(object):
             dev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
         elif dt == 'f16':
             dev = torch.from_numpy(f32_to_f16_bits(Wp).view(np.int16)).to(self.device)
-        elif self.split:
+        elif dt == 'f32s':
             dev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
         else:
             dev = torch.from_numpy(np.ascontiguousarray(Wp, np.float32)).to(self.device)
@@ -320,7 +340,7 @@ class CompiledGraph(object):
         if not self.mixed:
             return in_dt
         if result.is_output or not result.consumers:
-            return 'f32'
+            return self.dt
         for c in result.consumers:
             if c.kind == 'conv2d' and c.inputs[0] is result and self._is_half_conv(c):
                 continue
@@ -332,7 +352,7 @@ class CompiledGraph(object):
                     total = self._only_consumer(c, 'relu') or c
                     if self._store_dt(total, 'f16') == 'f16':
                         continue
-            return 'f32'
+            return self.dt
         return 'f16'
 
     def _dev_f32(self, arr):
@@ -590,13 +610,13 @@ class CompiledGraph(object):
             return None        # mixed mode: the two inputs would differ in type
         return A
 
-    def _chain_partner(self, result, k, cout, dt):
+    def _chain_partner(self, result, k, cout, dt, parts=None):
         """The 1x1 convolution (batch norm, no biases, stride 1, 32 or 64 filters) among the
         consumers of `result` that can run in the same launch as the 1x1 convolution producing
         `result` (fss_conv1x1_chain_nhwc: the end of one bottleneck unit and the first layer of
         the next, where both are bound by the bytes of `result`)."""
         if (not self.fuse_chain or dt != 'bf16' or k not in (32, 64, 128) or cout not in (128, 256)
-                or result.is_output):
+                or result.is_output or any(p % 32 for p in (parts or (k,)))):
             return None
         for c in result.consumers:
             if c.kind != 'conv2d' or c.inputs[0] is not result or c in self.fused or c in self.dual:
@@ -647,7 +667,7 @@ class CompiledGraph(object):
         epilogue of the convolution producing `result` (fss_conv2d_dual_head_nhwc)."""
         if not self.fuse_head or self.mfma_edge != 16 or cout % 32 or cout > 256:
             return None
-        if dt != 'bf16' and not (dt == 'f32' and self.split):
+        if dt not in ('bf16', 'f32s'):
             return None
         c = self._only_consumer(result, 'conv2d')
         if c is None or c in self.dual or self._dual_partner(c) is not None:
@@ -847,7 +867,7 @@ class CompiledGraph(object):
         self.param_bytes += cout * k * _ESZ[x.dt]
         name = b['weights'].rsplit('/', 1)[0] + '+' + A.attrs['weights'].rsplit('/', 2)[-2]
         if (kh, kw, b['rate'], b['pad_top'], b['pad_left']) == (1, 1, 1, 0, 0) and (h, w) == (ho, wo):
-            nxt = self._chain_partner(result, k, cout, x.dt)
+            nxt = self._chain_partner(result, k, cout, x.dt, parts=(cin, cin2))
             if nxt is not None:
                 return self._emit_chain(nxt, (A, B, add, result), x, x2, Wp[:cout, :k], bA + bB, None, act, name)
         head = self._head_partner(result, cout, x.dt)
@@ -1012,7 +1032,9 @@ class CompiledGraph(object):
                 return self._emit_chain(nxt, nodes, x, None, Wp[:cout, :cin], bias, res, act,
                                         a['weights'].rsplit('/', 1)[0])
         if (self.resident_3x3 and (kh, kw) == (3, 3) and pc == cin == 64 and cout in (64, 128)
-                and in_dt in ('bf16', 'f16') and out_dt == in_dt and res is None and a['biases'] is None and h * w * x.ld < 2 ** 31
+                and in_dt in ('bf16', 'f16') and out_dt == in_dt and res is None and a['biases'] is None
+                and k_pad == 9 * 64 and a['stride'] <= 4 and a['rate'] <= 8 and x.ld % 8 == 0
+                and (h + 2 * a['rate'] + a['pad_top']) * w * x.ld < 2 ** 31 - 1 and ho * wo < 2 ** 31 - 1
                 and (cout == 128 or a['stride'] == 2 or (a['stride'], a['rate']) == (1, 1))):
             # 64 input channels: the filter stays in LDS, the activations go straight to the MFMAs
             # (measured faster than the implicit GEMM for 128 filters and for stride 2: `Conv_2`
@@ -1679,6 +1701,11 @@ class CompiledGraph(object):
             t = t[:, :h, :w, v.coff:v.coff + c]
             if t.dtype in (torch.bfloat16, torch.float16):
                 t = t.float()
+            if v.dt == 'f32s':
+                # whole groups of 8 channels, decoded on the host
+                c0, c1 = v.coff // 8 * 8, -(-(v.coff + c) // 8) * 8
+                raw = v.buf.reshape(v.buf.shape[0], v.buf.shape[1], v.buf.shape[2], -1)[:, :h, :w, c0:c1].cpu().numpy()
+                return np.ascontiguousarray(split_bf16_decode(raw)[..., v.coff - c0:v.coff - c0 + c])
             out = t.cpu()
         return out.numpy()
 

@@ -285,7 +285,9 @@ int fss_avgpool_pyramid_nhwc(const void* x, void* const* y, const int* kh, const
  * array of FSS_PYRAMID_STATIC_MAX_BYTES inside the library (every GPU the library runs on
  * holds one copy until the process ends); n*h*sum(bw)*c*4 bytes beyond that are rejected
  * with an error.  The call allocates and frees nothing; its first call on a device (or
- * fss_set_device) looks the array's device address up once.  Every call on one GPU uses
+ * fss_set_device) looks the array's device address up once, which may load the library's code
+ * object: callers that capture the call into a graph make fss_set_device, or one plain
+ * warm-up call on that device, come first.  Every call on one GPU uses
  * that GPU's array, so two calls that overlap on one GPU (different streams) race; calls
  * ordered on one stream are safe.  Results are bit-identical to fss_avgpool_pyramid_nhwc. */
 #define FSS_PYRAMID_STATIC_MAX_BYTES (32u << 20)

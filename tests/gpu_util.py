@@ -6,11 +6,18 @@ import numpy as np
 import torch
 
 from fss import _lib
-from fss.plan import f32_to_bf16_bits, f32_to_f16_bits, f32_split_bf16_rows
+from fss.plan import f32_to_bf16_bits, f32_to_f16_bits, f32_split_bf16_rows, split_bf16_decode, split_bf16_encode
 
-# 'f32x3': float32 tensors; convolutions take them as FSS_F32_BF16X3 (split-bf16 products)
+# 'f32x3': split-bfloat16 tensors (FSS_F32_BF16X3: 4-byte slots, per 8 channels 8 bf16 high parts
+# then 8 bf16 remainders); convolutions form their products from them as three bf16 MFMAs
 DT = {'f32': (_lib.F32, torch.float32, 4), 'bf16': (_lib.BF16, torch.bfloat16, 8),
-      'f32x3': (_lib.F32, torch.float32, 4), 'f16': (_lib.F16, torch.float16, 8)}
+      'f32x3': (_lib.F32_BF16X3, torch.float32, 8), 'f16': (_lib.F16, torch.float16, 8)}
+
+
+def x3_round(a):
+    """float32 -> the nearest value a split-bfloat16 tensor holds (about 16 significant bits)."""
+    a = np.asarray(a, np.float32)
+    return split_bf16_decode(split_bf16_encode(a.reshape(-1, 8))).reshape(a.shape)
 
 
 def half_bits(a, dt):
@@ -24,7 +31,7 @@ def f16_round(a):
 
 
 def conv_in_code(dt):
-    return _lib.F32_BF16X3 if dt == 'f32x3' else DT[dt][0]
+    return DT[dt][0]
 
 
 def bf16_round(a):
@@ -34,13 +41,23 @@ def bf16_round(a):
 
 
 def to_dev(a, dt):
-    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if dt == 'f32x3':
+        a = split_bf16_encode(a)
+    t = torch.from_numpy(a).cuda()
     return t.to(DT[dt][1]).contiguous()
 
 
-def to_host(t):
+def to_host(t, dt=None, c=None, fill=-77.0):
+    """Device tensor -> float32 host array.  dt 'f32x3': decoded from its split-bfloat16 form.
+    c: logical channel count of a tensor with a wider pixel stride; the channels past it must
+    still hold `fill` (checked on the raw bytes), and only the first c are returned."""
     torch.cuda.synchronize()
-    return t.float().cpu().numpy()
+    raw = t.float().cpu().numpy()
+    if c is not None and c != raw.shape[-1]:
+        assert np.all(raw[..., c:] == fill), 'kernel wrote outside its channels'
+        raw = np.ascontiguousarray(raw[..., :c])
+    return split_bf16_decode(raw) if dt == 'f32x3' else raw
 
 
 def pack_conv_weights(w, dt, cin_phys=None):
@@ -93,10 +110,7 @@ def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw
                   bd.data_ptr() if bd is not None else None,
                   rd.data_ptr() if rd is not None else None, y.data_ptr(), None)
     _lib.call('fss_device_sync')
-    out = to_host(y)
-    if ld != cout:
-        assert np.all(out[..., cout:] == -77.0), 'kernel wrote outside its channel slice'
-    return out[..., :cout]
+    return to_host(y, out_dt, cout)
 
 
 def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, act=None, dt='bf16',
@@ -130,7 +144,7 @@ def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, 
     _lib.call('fss_conv2d_dual_nhwc', ctypes.byref(d), xd.data_ptr(), x2d.data_ptr(), cin2,
               wdev.data_ptr(), bd.data_ptr(), None, y.data_ptr(), None)
     _lib.call('fss_device_sync')
-    return to_host(y)
+    return to_host(y, out_dt)
 
 
 def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), out_hw=None, act='relu',
@@ -269,7 +283,7 @@ def zoomed_dilated_conv(x, w, dt='f32'):
     _lib.call('fss_zoom2_conv_commute', outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
               outs[3].data_ptr(), r.data_ptr(), n, h, wd, cout, code, None)
     _lib.call('fss_device_sync')
-    return to_host(r)
+    return to_host(r, dt)
 
 
 def pack_stem_weights(w, dt):
@@ -308,10 +322,7 @@ def stem_conv(frames, w, bias, mean, scale, sub, logical_hw, stride, rate, pads,
               n, hr, wr, sub, logical_hw[0], logical_hw[1], m3, s3, cout, kh, kw, stride, rate,
               pads[0], pads[1], ho, wo, _lib.ACT_CODES[act], conv_in_code(dt), ld, None)
     _lib.call('fss_device_sync')
-    out = to_host(y)
-    if ld != cout:
-        assert np.all(out[..., cout:] == -77.0), 'kernel wrote outside its channel slice'
-    return out[..., :cout]
+    return to_host(y, dt, cout)
 
 
 def stem2_conv(frames, w1, b1, w2, b2, mean, scale, sub, logical_hw, pads1, hw1, act1, pads2, hw2, act2,
@@ -357,4 +368,4 @@ def avgpool_pyramid(x, levels, dt):
     _lib.call('fss_avgpool_pyramid_nhwc', xd.data_ptr(), ptrs, kh, kw, bh, bw, L, work.data_ptr(),
               work.numel() * 4, n, h, w, c, DT[dt][0], None)
     _lib.call('fss_device_sync')
-    return [to_host(o) for o in outs]
+    return [to_host(o, dt) for o in outs]

@@ -545,6 +545,8 @@ def test_stem_conv_u8_matches_preprocess_resize_conv(case, dt):
     bias -> activation of the oracle, built from the separate oracle ops."""
     gu = _gu()
     (hr, wr), (hp, wp), sub, k, stride, rate, cout, act, y_ld = case
+    if dt == 'f32x3' and cout % 8:
+        pytest.skip('split-bf16 tensors hold channels in groups of 8')
     rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
     frames = rng.integers(0, 256, (2, hr, wr, 3)).astype(np.uint8)
     mean, scale = (123.68, 116.779, 103.939), (1.0, 0.5, 2.0)
@@ -684,7 +686,7 @@ def _call(name, *args):
     _lib().call('fss_device_sync')
 
 
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 def test_depthwise(dt):
     gu, L = _gu(), _lib()
     rng = np.random.default_rng(3)
@@ -698,8 +700,8 @@ def test_depthwise(dt):
         x = rng.normal(0, 1, (n, h, wd, c)).astype(np.float32)
         w = rng.normal(0, 0.4, (3, 3, c, 1)).astype(np.float32)
         bias = rng.normal(0, 0.5, c).astype(np.float32)
-        if dt == 'bf16':
-            x = gu.bf16_round(x)
+        if dt != 'f32':
+            x = gu.bf16_round(x) if dt == 'bf16' else gu.x3_round(x)
         ref = O.relu6(O.depthwise_conv2d(x, w, stride, rate, np.float64) + bias)
         ho, pt, _ = O.same_padding(h, 3, stride, rate)
         wo, pl, _ = O.same_padding(wd, 3, stride, rate)
@@ -709,18 +711,18 @@ def test_depthwise(dt):
         y = torch.empty((n, ho, wo, c), dtype=gu.DT[dt][1], device='cuda')
         _call('fss_dwconv2d_nhwc', xd.data_ptr(), wdv.data_ptr(), bd.data_ptr(), y.data_ptr(),
               n, h, wd, c, 3, 3, stride, rate, pt, pl, ho, wo, L.ACT_RELU6, gu.DT[dt][0], None)
-        _close(gu.to_host(y), ref, 2e-4 if dt == 'f32' else 1.0 / 128, 'depthwise')
+        _close(gu.to_host(y, dt), ref, {'f32': 2e-4, 'f32x3': 2e-5}.get(dt, 1.0 / 128), 'depthwise')
 
 
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 def test_pools_and_subsample(dt):
     gu = _gu()
     rng = np.random.default_rng(4)
     code, tdt, epc = gu.DT[dt]
     for (n, h, wd, c) in [(1, 37, 41, 64), (2, 40, 52, 16)]:
         x = rng.normal(0, 1, (n, h, wd, c)).astype(np.float32)
-        if dt == 'bf16':
-            x = gu.bf16_round(x)
+        if dt != 'f32':
+            x = gu.bf16_round(x) if dt == 'bf16' else gu.x3_round(x)
         xd = gu.to_dev(x, dt)
         # max pool 3x3/2 SAME: exact (selection only)
         ref = O.max_pool_same(x, 3, 2)
@@ -729,13 +731,13 @@ def test_pools_and_subsample(dt):
         y = torch.empty((n, ho, wo, c), dtype=tdt, device='cuda')
         _call('fss_maxpool_nhwc', xd.data_ptr(), y.data_ptr(), n, h, wd, c, 3, 2, pt, pl, ho, wo,
               code, None)
-        assert np.array_equal(gu.to_host(y), ref)
+        assert np.array_equal(gu.to_host(y, dt), ref)
         # subsample: exact
         ref = O.subsample(x, 2)
         y = torch.empty(ref.shape, dtype=tdt, device='cuda')
         _call('fss_subsample_nhwc', xd.data_ptr(), y.data_ptr(), n, h, wd, c, 2, ref.shape[1],
               ref.shape[2], code, None)
-        assert np.array_equal(gu.to_host(y), ref)
+        assert np.array_equal(gu.to_host(y, dt), ref)
         # avg pool bins, including dropped remainder rows / columns
         for f in (1, 2, 3, 4, 6):
             kh, kw = int(h / f), int(wd / f)
@@ -743,7 +745,7 @@ def test_pools_and_subsample(dt):
             y = torch.empty(ref.shape, dtype=tdt, device='cuda')
             _call('fss_avgpool_bins_nhwc', xd.data_ptr(), y.data_ptr(), n, h, wd, c, kh, kw,
                   ref.shape[1], ref.shape[2], code, None)
-            _close(gu.to_host(y), ref, 1e-5 if dt == 'f32' else 1.0 / 128, 'avgpool f=%d' % f)
+            _close(gu.to_host(y, dt), ref, {'f32': 1e-5, 'f32x3': 2e-5}.get(dt, 1.0 / 128), 'avgpool f=%d' % f)
         # all levels of a pyramid pooling module in one pass (dropped remainders included)
         for factors in ((1, 2, 3, 4), (1, 2, 3, 6), (2,)):
             levels = [(int(h / f), int(wd / f)) for f in factors]
@@ -751,10 +753,10 @@ def test_pools_and_subsample(dt):
             for (kh, kw), g in zip(levels, got):
                 ref = O.avg_pool_valid(x.astype(np.float64), kh, kw)
                 assert g.shape == ref.shape
-                _close(g, ref, 1e-5 if dt == 'f32' else 1.0 / 128, 'pyramid avgpool %dx%d' % (kh, kw))
+                _close(g, ref, {'f32': 1e-5, 'f32x3': 2e-5}.get(dt, 1.0 / 128), 'pyramid avgpool %dx%d' % (kh, kw))
 
 
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 def test_avgpool_pyramid_large_batch_path(dt):
     """fss_avgpool_pyramid_nhwc switches its first stage with the problem size (column pieces
     for small batches, whole rows for large ones).  The small form is checked against the
@@ -766,6 +768,10 @@ def test_avgpool_pyramid_large_batch_path(dt):
     assert n * h * (c // epc) >= 262144
     g = torch.Generator(device='cuda').manual_seed(1)
     xd = torch.randn((n, h, wd, c), device='cuda', generator=g).to(tdt)
+    if dt == 'f32x3':
+        # a valid split-bfloat16 tensor made on the device: bf16 high parts, zero remainders
+        hi = xd.to(torch.bfloat16).view(n, h, wd, c // 8, 1, 8)
+        xd = torch.cat([hi, torch.zeros_like(hi)], dim=4).contiguous().view(torch.float32).view(n, h, wd, c)
     levels = [(int(h / f), int(wd / f)) for f in (1, 2, 3, 4)]
     Lv = len(levels)
     outs = [torch.full((n, h // kh, wd // kw, c), -77.0, dtype=tdt, device='cuda') for kh, kw in levels]
@@ -781,10 +787,10 @@ def test_avgpool_pyramid_large_batch_path(dt):
         ref = torch.empty_like(o)
         _call('fss_avgpool_bins_nhwc', xd.data_ptr(), ref.data_ptr(), n, h, wd, c, kh, kw, h // kh, wd // kw,
               code, None)
-        _close(gu.to_host(o), gu.to_host(ref), 1e-5 if dt == 'f32' else 1.0 / 128, 'pyramid rows %dx%d' % (kh, kw))
+        _close(gu.to_host(o, dt), gu.to_host(ref, dt), {'f32': 1e-5, 'f32x3': 2e-5}.get(dt, 1.0 / 128), 'pyramid rows %dx%d' % (kh, kw))
 
 
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 def test_resize_bilinear(dt):
     gu = _gu()
     rng = np.random.default_rng(5)
@@ -795,8 +801,8 @@ def test_resize_bilinear(dt):
              ((1, 1025 // 8, 2049 // 8, 8), (512 // 8 + 1, 129), True)]
     for shape, (ho, wo), align in cases:
         x = rng.normal(0, 1, shape).astype(np.float32)
-        if dt == 'bf16':
-            x = gu.bf16_round(x)
+        if dt != 'f32':
+            x = gu.bf16_round(x) if dt == 'bf16' else gu.x3_round(x)
         ref = O.resize_bilinear(x, ho, wo, align)
         xd = gu.to_dev(x, dt)
         n, h, wd, c = shape
@@ -804,7 +810,7 @@ def test_resize_bilinear(dt):
         _call('fss_resize_bilinear_nhwc', xd.data_ptr(), y.data_ptr(), n, h, wd, c, ho, wo, c,
               1 if align else 0, code, None)
         # same float32 formula as the oracle: exact for f32 up to fma contraction
-        _close(gu.to_host(y), ref, 2e-6 if dt == 'f32' else 1.0 / 128, 'resize %s' % (shape,))
+        _close(gu.to_host(y, dt), ref, {'f32': 2e-6, 'f32x3': 2e-5}.get(dt, 1.0 / 128), 'resize %s' % (shape,))
     # float32 logits with 19 channels (scalar path) into a strided destination
     x = rng.normal(0, 1, (1, 9, 11, 19)).astype(np.float32)
     ref = O.resize_bilinear(x, 17, 21, True)
@@ -817,21 +823,21 @@ def test_resize_bilinear(dt):
     assert np.all(got[..., 19:] == 0)
 
 
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 def test_pyramid_add(dt):
     gu = _gu()
     rng = np.random.default_rng(6)
     code, tdt, epc = gu.DT[dt]
     n, h, wd, c = 2, 33, 65, 64
     x = rng.normal(0, 1, (n, h, wd, c)).astype(np.float32)
-    if dt == 'bf16':
-        x = gu.bf16_round(x)
+    if dt != 'f32':
+        x = gu.bf16_round(x) if dt == 'bf16' else gu.x3_round(x)
     pooled = []
     ref = x.astype(np.float32)
     for f in (1, 2, 3, 4):
         p = O.avg_pool_valid(x, int(h / f), int(wd / f)).astype(np.float32)
-        if dt == 'bf16':
-            p = gu.bf16_round(p)
+        if dt != 'f32':
+            p = gu.bf16_round(p) if dt == 'bf16' else gu.x3_round(p)
         pooled.append(p)
         ref = ref + O.resize_bilinear(p, h, wd, True)
     xd = gu.to_dev(x, dt)
@@ -842,32 +848,32 @@ def test_pyramid_add(dt):
     bw = (ctypes.c_int * 4)(*[p.shape[2] for p in pooled])
     _call('fss_pyramid_add_nhwc', xd.data_ptr(), ptrs, bh, bw, 4, y.data_ptr(), n, h, wd, c, code,
           None)
-    _close(gu.to_host(y), ref, 2e-6 if dt == 'f32' else 1.0 / 128, 'pyramid')
+    _close(gu.to_host(y, dt), ref, {'f32': 2e-6, 'f32x3': 2e-5}.get(dt, 1.0 / 128), 'pyramid')
     # without a base tensor: the sum of the resized maps alone
     y.fill_(-5.0)
     _call('fss_pyramid_add_nhwc', None, ptrs, bh, bw, 4, y.data_ptr(), n, h, wd, c, code, None)
-    _close(gu.to_host(y), ref - x, 2e-6 if dt == 'f32' else 1.0 / 128, 'pyramid sum without a base')
+    _close(gu.to_host(y, dt), ref - x, {'f32': 2e-6, 'f32x3': 2e-5}.get(dt, 1.0 / 128), 'pyramid sum without a base')
 
 
-@pytest.mark.parametrize('dt', ['f32', 'bf16'])
+@pytest.mark.parametrize('dt', ['f32', 'bf16', 'f32x3'])
 def test_add_copy_preprocess(dt):
     gu, L = _gu(), _lib()
     rng = np.random.default_rng(8)
     code, tdt, epc = gu.DT[dt]
     a = rng.normal(0, 3, (2, 5, 7, 16)).astype(np.float32)
     b = rng.normal(0, 3, (2, 5, 7, 16)).astype(np.float32)
-    if dt == 'bf16':
-        a, b = gu.bf16_round(a), gu.bf16_round(b)
+    if dt != 'f32':
+        a, b = (gu.bf16_round(a), gu.bf16_round(b)) if dt == 'bf16' else (gu.x3_round(a), gu.x3_round(b))
     ad, bd = gu.to_dev(a, dt), gu.to_dev(b, dt)
     y = torch.empty_like(ad)
     _call('fss_add_act', ad.data_ptr(), bd.data_ptr(), y.data_ptr(), a.size, L.ACT_RELU, code, None)
-    _close(gu.to_host(y), O.relu(a + b), 1e-6 if dt == 'f32' else 1.0 / 128, 'add')
+    _close(gu.to_host(y, dt), O.relu(a + b), {'f32': 1e-6, 'f32x3': 2e-5}.get(dt, 1.0 / 128), 'add')
     # channel copy into a concat slice
     big = torch.zeros((2, 5, 7, 48), dtype=tdt, device='cuda')
     esz = big.element_size()
     _call('fss_copy_channels', ad.data_ptr(), 16, big.data_ptr() + 16 * esz, 48, 2 * 5 * 7, 16, code,
           None)
-    got = gu.to_host(big)
+    got = gu.to_host(big, dt)
     assert np.array_equal(got[..., 16:32], a) and np.all(got[..., :16] == 0) and np.all(got[..., 32:] == 0)
     # preprocess: zero pad BEFORE mean subtraction
     img = rng.integers(0, 256, (2, 10, 12, 3)).astype(np.uint8)
@@ -878,8 +884,8 @@ def test_add_copy_preprocess(dt):
     y = torch.empty((2, 11, 13, epc), dtype=tdt, device='cuda')
     _call('fss_preprocess_u8', xd.data_ptr(), y.data_ptr(), 2, 10, 12, 11, 13, epc,
           mean.ctypes.data_as(L.c_float_p), scale.ctypes.data_as(L.c_float_p), code, None)
-    got = gu.to_host(y)
-    _close(got[..., :3], ref, 1e-6 if dt == 'f32' else 1.0 / 128, 'preprocess')
+    got = gu.to_host(y, dt)
+    _close(got[..., :3], ref, {'f32': 1e-6, 'f32x3': 2e-5}.get(dt, 1.0 / 128), 'preprocess')
     assert np.all(got[..., 3:] == 0)
 
 

@@ -79,3 +79,49 @@ def test_static_scratch_pyramid_pool_rejects_oversize():
     with pytest.raises(L.FssError, match='FSS_PYRAMID_STATIC_MAX_BYTES'):
         L.call('fss_avgpool_pyramid_nhwc_static', xd.data_ptr(), ptrs, khs, kws, bhs, bws, Lv,
                n, h, wd, c, code, None)
+
+
+def test_static_scratch_pyramid_pool_under_graph_capture():
+    """The use the entry point is for: after one warm-up call on the device (which resolves the
+    static array's address; fss_set_device does the same), the call is stream-captured into a
+    hipGraph, replayed twice, gives the workspace form's bits, and device memory in use does not
+    change across capture and replays."""
+    import gpu_util as gu
+    from fss import _lib as L
+    code, tdt, _ = gu.DT['bf16']
+    shape, factors = (2, 33, 65, 512), (1, 2, 3, 4)
+    n, h, wd, c = shape
+    levels = [(int(h / f), int(wd / f)) for f in factors]
+    g = torch.Generator(device='cuda').manual_seed(9)
+    xd = torch.randn(shape, device='cuda', generator=g).to(tdt)
+    ref, got = _pool_both(L, xd, levels, code, tdt)           # also the warm-up call
+    Lv = len(levels)
+    khs = (ctypes.c_int * Lv)(*[l[0] for l in levels])
+    kws = (ctypes.c_int * Lv)(*[l[1] for l in levels])
+    bhs = (ctypes.c_int * Lv)(*[h // l[0] for l in levels])
+    bws = (ctypes.c_int * Lv)(*[wd // l[1] for l in levels])
+    outs = [torch.full((n, h // kh, wd // kw, c), -77.0, dtype=tdt, device='cuda') for kh, kw in levels]
+    ptrs = (ctypes.c_void_p * Lv)(*[o.data_ptr() for o in outs])
+    stream = torch.cuda.Stream()
+    sh = ctypes.c_void_p(stream.cuda_stream)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    L.call('fss_capture_begin', sh)
+    ex = ctypes.c_void_p()
+    try:
+        L.call('fss_avgpool_pyramid_nhwc_static', xd.data_ptr(), ptrs, khs, kws, bhs, bws, Lv, n, h, wd, c, code, sh)
+    finally:
+        L.call('fss_capture_end', sh, ctypes.byref(ex))
+    for _ in range(2):
+        for o in outs:
+            o.fill_(-77.0)
+        torch.cuda.synchronize()
+        L.call('fss_graph_launch', ex, sh)
+        L.call('fss_stream_sync', sh)
+        for r, o in zip(ref, outs):
+            assert np.array_equal(r, o.contiguous().view(torch.uint8).cpu().numpy())
+    free_after = torch.cuda.mem_get_info()[0]
+    L.call('fss_device_sync')
+    L.call('fss_graph_destroy', ex)
+    # the executable graph itself takes a little driver memory; a 32 MiB scratch allocation would show
+    assert free_before - free_after < (8 << 20), (free_before, free_after)

@@ -1,6 +1,6 @@
 """Micro-benchmark of fss_conv2d_nhwc on one layer shape (random data).
 
-usage: python tools/conv_micro.py [name] [--dtype bf16|f32] [--iters N] [--batch B]
+usage: python tools/conv_micro.py [name] [--dtype bf16|f16|f32|f32x3] [--iters N] [--batch B]
 Shapes are ICNet-1.0 layers at 1025x2049.  Prints ms and TFLOP/s (HIP events).
 """
 import argparse
@@ -63,7 +63,7 @@ def main():
         res = torch.randn((n, ho, wo, cout), device='cuda', generator=g).to(tdt) if has_res else None
         y = torch.empty((n, ho, wo, cout), device='cuda', dtype=tdt)
         d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=k, kw=k, stride=stride, dilation=rate,
-                          pad_top=pt, pad_left=pl, ho=ho, wo=wo, act=1, in_dtype=code, out_dtype=code,
+                          pad_top=pt, pad_left=pl, ho=ho, wo=wo, act=1, in_dtype=gu.conv_in_code(args.dtype), out_dtype=code,
                           y_ld=cout, res_ld=cout, k_pad=k_pad, cout_pad=cout_pad, config=args.cfg)
         torch.cuda.synchronize()
 

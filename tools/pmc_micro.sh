@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over tools/conv_micro.py:  tools/pmc_micro.sh <layer> <cfg> [batch]
+# PMC passes over tools/conv_micro.py:  [DTYPE=bf16|f16|f32x3] tools/pmc_micro.sh <layer> <cfg> [batch]
 # One rocprofv3 run per counter group; prints per-dispatch averages for the conv kernel.
 set -o pipefail
 L=${1:-cff1_dil}; C=${2:-3}; B=${3:-16}
@@ -13,7 +13,7 @@ for grp in \
  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
  "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_IFETCH SQ_INSTS_SMEM" ; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -o p -- python3 tools/conv_micro.py $L --cfg $C --batch $B --iters 3 > $OUT/g$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/g$i.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -o p -- python3 tools/conv_micro.py $L --cfg $C --batch $B --iters 3 --dtype ${DTYPE:-bf16} > $OUT/g$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/g$i.log; exit 1; }
 done
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections
