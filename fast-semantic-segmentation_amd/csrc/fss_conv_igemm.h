@@ -614,8 +614,8 @@ conv_igemm_kernel(const ConvArgs a) {
               for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.25f; d1[e] += r1[e] * 0.25f; }
             }
           } else {
-            // split-bfloat16 sources (32 bytes per 8 channels): the addresses of the (up to) four
-            // sources first
+            // float sources (32 bytes per 8 channels): the addresses of the (up to) four sources
+            // first
             const unsigned zbase = (zo[i] & ~15u) + (unsigned)(32 * s) * ESZ;
             const unsigned zdr = (zo[i] & 1u) ? zrow : 0u, zdc = (zo[i] & 2u) ? zpix : 0u;
             const bool two = zeven[i] && !zborder[i];
@@ -652,27 +652,20 @@ conv_igemm_kernel(const ConvArgs a) {
                 src[nb] = base + off;
               }
             }
-            // split-bfloat16 sources: the high parts (first 16 bytes of the group) and the
-            // remainders (second 16 bytes) are summed over the sources one after the other, so
-            // that at most four loaded vectors are live; value = high part + remainder is linear
+            // the sources are plain floats here (nothing else reads them, so their producer skips
+            // the split): 8 channels = two 16-byte loads per source, summed as they arrive
             float r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            auto add8 = [&](const uint4& t) {
-              r8[0] += __uint_as_float(t.x << 16); r8[1] += __uint_as_float(t.x & 0xffff0000u);
-              r8[2] += __uint_as_float(t.y << 16); r8[3] += __uint_as_float(t.y & 0xffff0000u);
-              r8[4] += __uint_as_float(t.z << 16); r8[5] += __uint_as_float(t.z & 0xffff0000u);
-              r8[6] += __uint_as_float(t.w << 16); r8[7] += __uint_as_float(t.w & 0xffff0000u);
-            };
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-              const uint4 t0 = *reinterpret_cast<const uint4*>(src[0] + 16 * hh);
-              const uint4 t1 = *reinterpret_cast<const uint4*>(src[1] + 16 * hh);
-              if (two) {
-                add8(t0); add8(t1);
-              } else {
-                const uint4 t2 = *reinterpret_cast<const uint4*>(src[2] + 16 * hh);
-                const uint4 t3 = *reinterpret_cast<const uint4*>(src[3] + 16 * hh);
-                add8(t0); add8(t1); add8(t2); add8(t3);
+              const float4 t0 = *reinterpret_cast<const float4*>(src[0] + 16 * hh);
+              const float4 t1 = *reinterpret_cast<const float4*>(src[1] + 16 * hh);
+              float4 t = make_float4(t0.x + t1.x, t0.y + t1.y, t0.z + t1.z, t0.w + t1.w);
+              if (!two) {
+                const float4 t2 = *reinterpret_cast<const float4*>(src[2] + 16 * hh);
+                const float4 t3 = *reinterpret_cast<const float4*>(src[3] + 16 * hh);
+                t.x += t2.x + t3.x; t.y += t2.y + t3.y; t.z += t2.z + t3.z; t.w += t2.w + t3.w;
               }
+              r8[4 * hh] = t.x; r8[4 * hh + 1] = t.y; r8[4 * hh + 2] = t.z; r8[4 * hh + 3] = t.w;
             }
             const float zsc = two ? 0.5f : 0.25f;
 #pragma unroll
@@ -699,7 +692,7 @@ conv_igemm_kernel(const ConvArgs a) {
             }
           }
         }
-        auto cl = [&](float v) { return fminf(fmaxf(v, act_lo), act_hi); };
+        auto cl = [&](float v) { return __builtin_amdgcn_fmed3f(v, act_lo, act_hi); };
         const float v8[8] = {cl(d0[0] + b0.x), cl(d0[1] + b0.y), cl(d0[2] + b0.z), cl(d0[3] + b0.w),
                              cl(d1[0] + b1.x), cl(d1[1] + b1.y), cl(d1[2] + b1.z), cl(d1[3] + b1.w)};
         if constexpr (SPLIT) {
@@ -975,11 +968,13 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   X(31, 128, 128, 2, 4, 64, 3, 16)  \
   X(32, 128, 64, 4, 2, 128, 2, 16)  \
   X(33, 128, 256, 2, 4, 64, 2, 16)  \
-  X(34, 128, 256, 2, 4, 64, 3, 16)
+  X(34, 128, 256, 2, 4, 64, 3, 16)  \
+  X(36, 64, 256, 1, 4, 128, 2, 16)  \
+  X(37, 128, 256, 2, 4, 128, 2, 16)
 // configuration 35: the 8-wave, 8-phase 256x256 kernel of fss_conv8.hip (bf16 in and out, cin in
 // whole K tiles); for every other layer it stands for configuration 28, whose results are the same
 static constexpr int kConv8Config = 35;
-static constexpr int kNumConvConfigs = 35;
+static constexpr int kNumConvConfigs = 37;
 
 // automatic choice when the caller does not name a configuration
 static int default_config(const ConvArgs& a) {

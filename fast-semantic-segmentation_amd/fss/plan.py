@@ -777,6 +777,10 @@ class CompiledGraph(object):
         self._emit('copy', base + '/border_crops', 'fss_zoom2_border_gather',
                    (xl.ptr, tb.ptr, lr.ptr, cn.ptr, n, h, w, cin, _CODE[dt], self.sh),
                    nbytes=2 * crop_px * cin * esz)
+        head = self._head_partner(result, cout, dt) if cin2 % 64 == 0 else None
+        # results only the classifier launch reads (it interpolates them itself) stay plain
+        # float in the split mode: nothing multiplies them, so splitting them would be wasted
+        ydt = 'f32' if (dt == 'f32s' and head is not None and self.fuse_zoom_residual) else dt
         ys = []
         # the crops are convolved without padding across their 3 rows / columns: only the
         # middle row / column / pixel comes out
@@ -784,10 +788,10 @@ class CompiledGraph(object):
                                ('@corners', cn, 0, 0)):
             nn, hh, ww, _ = v.shape
             oh, ow = (hh if pt else 1), (ww if pl else 1)
-            y = Val(self._alloc((nn, oh, ow, cout), dt), (nn, oh, ow, cout), dt)
+            y = Val(self._alloc((nn, oh, ow, cout), ydt), (nn, oh, ow, cout), ydt)
             d = _lib.ConvDesc(n=nn, h=hh, w=ww, cin=cin, cout=cout, kh=3, kw=3, stride=1, dilation=1,
                               pad_top=pt, pad_left=pl, ho=oh, wo=ow, act=_lib.ACT_CODES[None],
-                              in_dtype=self._in_code(dt), out_dtype=_CODE[dt], y_ld=y.ld, res_ld=0,
+                              in_dtype=self._in_code(dt), out_dtype=_CODE[ydt], y_ld=y.ld, res_ld=0,
                               k_pad=k_pad, cout_pad=cout_pad)
             self._emit('conv', base + tag, 'fss_conv2d_nhwc',
                        (ctypes.byref(d), v.ptr, wB.data_ptr(), None, None, y.ptr, self.sh),
@@ -796,7 +800,6 @@ class CompiledGraph(object):
                        graph_flops=0)
             ys.append(y)
         self.temps.extend([tb, lr, cn] + ys)        # buffers no graph node owns
-        head = self._head_partner(result, cout, dt) if cin2 % 64 == 0 else None
         r = None
         if head is None or not self.fuse_zoom_residual:
             r = Val(self._alloc((n, ho, wo, cout), dt), (n, ho, wo, cout), dt)

@@ -30,14 +30,20 @@ extern "C" {
 
 #define FSS_F32 0
 #define FSS_BF16 1
-/* fss_conv_desc.in_dtype and the dtype of fss_stem_conv_u8 only: float tensors exactly as FSS_F32, but every product is formed on
- * the bf16 matrix pipe from a two-way bf16 split of both operands (a_hi*b_hi + a_hi*b_lo +
- * a_lo*b_hi with hi = bf16(v), lo = bf16(v - hi), float accumulation): about 16 mantissa bits
- * per operand, i.e. results of float quality (well inside 1e-3 of the logit scale) at several
- * times the speed of the float MFMAs.  Activations, residual, bias and output are float; the
- * packed weights have the FSS_F32 dimensions and byte size, but every 8 consecutive k values
- * of a row are stored as their 8 bf16 high parts followed by their 8 bf16 remainders.
- * Needs a tile configuration with an even number of k steps per tile. */
+/* Split-bfloat16 tensors: float values stored as two bfloat16 numbers each, hi = bf16(v) and
+ * lo = bf16(v - hi) (about 16 mantissa bits).  A tensor keeps the float layout's size and
+ * strides (4 bytes per element, strides and channel counts in elements), but every aligned
+ * group of 8 channels - 32 bytes - holds its 8 high parts followed by its 8 remainders, so
+ * channel counts, pixel strides and channel offsets are multiples of 8 and base addresses
+ * multiples of 32 bytes.  Convolutions form every product on the bf16 matrix pipe as
+ * a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with float accumulation: results of float quality (well
+ * inside 1e-3 of the logit scale) at several times the speed of the float MFMAs, and because
+ * producers split once when they store, the matrix pipe is fed from memory without any
+ * conversion.  Packed weights have the FSS_F32 dimensions and byte size with every 8
+ * consecutive k values of a row stored the same way.  Every entry point with a dtype
+ * argument takes it; a convolution may read it and store FSS_F32 (plain floats, e.g. class
+ * scores), FSS_F16 or FSS_F32_BF16X3.  Needs a tile configuration with an even number of k
+ * steps per tile. */
 #define FSS_F32_BF16X3 2
 /* IEEE half precision tensors (11 significant bits against bfloat16's 8, same bytes and the
  * same matrix-core rate): every product is one f16 MFMA with float accumulation, outputs are
@@ -100,10 +106,11 @@ typedef struct fss_conv_desc {
   int32_t pad_top, pad_left; /* zero padding before the first row / column */
   int32_t ho, wo;            /* output spatial size                        */
   int32_t act;               /* FSS_ACT_*                                  */
-  int32_t in_dtype;          /* FSS_F32 | FSS_BF16 | FSS_F16 (x, weights, residual) |
-                                FSS_F32_BF16X3 (float storage, split-bf16 MFMA) */
+  int32_t in_dtype;          /* FSS_F32 | FSS_BF16 | FSS_F16 | FSS_F32_BF16X3
+                                (x, weights, residual)                      */
   int32_t out_dtype;         /* FSS_F32 (any input) | FSS_BF16 (bf16 input) |
-                                FSS_F16 (FSS_F16 or FSS_F32_BF16X3 input)   */
+                                FSS_F16 or FSS_F32_BF16X3 (FSS_F16 or
+                                FSS_F32_BF16X3 input)                       */
   int32_t y_ld;              /* output pixel stride in elements (>= cout)  */
   int32_t res_ld;            /* residual pixel stride in elements          */
   int32_t k_pad, cout_pad;   /* packed weight dims                         */
@@ -167,16 +174,17 @@ int fss_conv2d_dual_nhwc(const fss_conv_desc* desc, const void* x, const void* x
  * feature fusion + the `Predictions` slim.conv2d of architectures/icnet_architecture.py:
  * 131-142,238-252 (the classifier applied before the x2 upsampling, which commutes with a
  * 1x1 convolution).  desc->in_dtype FSS_BF16 (the rounding to bf16 in the formula above is
- * that mode's) or FSS_F32_BF16X3 (float tensors, nothing rounded: the activated values are
- * split like every other activation); cin (and cin2) multiples of 64; cout a multiple
+ * that mode's) or FSS_F32_BF16X3 (split-bfloat16 tensors, nothing rounded to 8 bits: the
+ * activated values are split like every other activation); cin (and cin2) multiples of 64; cout a multiple
  * of 32 and <= 256; cout_head <= 20; w_head: bf16 [32][cout], rows >= cout_head zero
  * (FSS_F32_BF16X3: [2][32][cout], the bf16 high parts of the float weights, then their bf16
  * remainders); desc->config: 0 or a 16x16-MFMA configuration whose block columns >= cout
  * (FSS_F32_BF16X3: with 128 bytes of K per tile row);
  * `residual`: [pixels][cout] of the activation type with pixel stride desc->res_ld, or NULL.
  * `zoom_residual` (or NULL): the residual given at half resolution, as the four tensors
- * {y, ytb, ylr, ycn} of fss_zoom2_conv_commute (activation type, cout channels, y: [n,zh,zw,cout],
- * ytb: [2n,1,zw,cout], ylr: [2n,zh,1,cout], ycn: [4n,1,1,cout]) and
+ * {y, ytb, ylr, ycn} of fss_zoom2_conv_commute (bfloat16 with FSS_BF16 input, plain FSS_F32
+ * with FSS_F32_BF16X3 input: nothing multiplies them, so their producer stores them unsplit;
+ * cout channels, y: [n,zh,zw,cout], ytb: [2n,1,zw,cout], ylr: [2n,zh,1,cout], ycn: [4n,1,1,cout]) and
  * interpolated in the epilogue instead of being read from a zoomed copy; ho = 2 zh - 1,
  * wo = 2 zw - 1.
  * desc->out_dtype and y_ld are ignored.  Equals fss_conv2d_dual_nhwc followed by
@@ -349,9 +357,10 @@ int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho,
  * architectures/icnet_architecture.py:153-160 'Conv',
  * third_party/mobilenet_v2.py first conv).  Weights: [cout_pad][k_pad] with
  * k = (r*kw + s)*4 + ch (ch 3 = 0), dims from fss_stem_pack_dims, batch norm
- * folded in.  dtype FSS_F32_BF16X3: float output of float quality from three bf16 MFMAs per
- * step; the packed weights are two bf16 matrices [cout_pad][k_pad], the high parts bf16(W)
- * followed by the remainders bf16(W - high), dims from fss_stem_pack_dims with that dtype.
+ * folded in.  dtype FSS_F32_BF16X3: split-bfloat16 output (cout and y_ld multiples of 8) of
+ * float quality from three bf16 MFMAs per step; the packed weights are two bf16 matrices
+ * [cout_pad][k_pad], the high parts bf16(W) followed by the remainders bf16(W - high), dims
+ * from fss_stem_pack_dims with that dtype.
  * Limits: cout <= 64, kh*kw <= 64, stride, dilation <= 4. */
 int fss_stem_pack_dims(int kh, int kw, int cout, int dtype, int* k_pad, int* cout_pad);
 int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const float* bias, void* y,

@@ -180,7 +180,8 @@ def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), ou
     bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda()
     bh = torch.from_numpy(np.asarray(b_head, np.float32)).cuda()
     rd = to_dev(residual, dt) if residual is not None else None
-    zd = [to_dev(t, dt) for t in zoom_residual] if zoom_residual is not None else None
+    # the interpolated sources of the split mode are plain float tensors
+    zd = [to_dev(t, 'f32' if dt == 'f32x3' else dt) for t in zoom_residual] if zoom_residual is not None else None
     zp = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in zd]) if zd else None
     zh, zw = (zd[0].shape[1], zd[0].shape[2]) if zd else (0, 0)
     ld = y_ld or ncls
