@@ -172,3 +172,27 @@ def test_benchmarked_plan_at_full_size_matches_oracle(config, fs):
             same = float((labels1[0] == labels[0]).mean())
             print('  batch-8 plan vs batch-1 plan: scores differ by %.3g of scale, labels agree %.5f' % (d, same))
             assert d <= 2e-2 and same >= 0.97
+
+
+@pytest.mark.parametrize('name', ['pspnet713_bs8', 'icnet05_bs32'])
+def test_other_configurations_at_their_stated_batch(name):
+    """PSPNet-50 713x713 at 8 frames per launch and the half-width ICNet at 32 (the batch sizes
+    their published figures are quoted on), in the default compute mode: the first and the last
+    frame of the batch - two different frames - against the numpy oracle at the stated label
+    floor, and a copy of the first frame in the middle of the batch gives the first frame's
+    labels bit for bit (no frame depends on its position or its neighbours)."""
+    import bench
+    cfg_file, in_shape, pad, b, arch, ext, fs, istd = bench.OTHER_CONFIGS[name]
+    cg, pred, _, weights = bench.build_plan(b, 'mixed', config=cfg_file, input_shape=in_shape, pad_shape=pad,
+                                            input_std=istd)
+    frames = np.random.default_rng(31).integers(0, 256, (b,) + in_shape, dtype=np.uint8)
+    frames[b // 2] = frames[0]
+    labels = cg.run(frames, [pred])[0]
+    del cg
+    assert labels.shape[0] == b
+    assert np.array_equal(labels[b // 2], labels[0])
+    for f in (0, b - 1):
+        ref = bench.oracle_labels(weights, frames[f:f + 1], arch, ext, fs, pad)
+        agree = float((labels[f, ..., 0] == ref[0]).mean())
+        print('%s frame %d of %d: argmax agreement %.5f' % (name, f, b, agree))
+        assert agree >= 0.999

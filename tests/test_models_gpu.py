@@ -516,3 +516,38 @@ def test_pruned_weights_run_in_the_half_width_model():
     logits, labels = plan.CompiledGraph(g, outs, pruned, dtype='float32').run(img)
     assert float(np.abs(logits - ref).max()) <= 1e-3 * float(np.abs(ref).max())
     assert (labels[..., 0] == O.argmax_channels(ref)).mean() >= 0.999
+
+
+@pytest.mark.parametrize('dtype,tol', [('float32', 1e-3), ('mixed', 1e-3), ('bfloat16', 2e-2)])
+def test_icnet_pretrain_single_branch_mode(dtype, tol):
+    """ICNet with pretrain_single_branch_mode (architectures/icnet_architecture.py:64-79: the
+    full-resolution backbone with its pyramid module alone, no second or third branch, logits
+    zoomed x8) through the HIP path against the oracle."""
+    from google.protobuf import text_format
+    from protos import pipeline_pb2
+    from builders import model_builder
+    from fss import graph as G, synth, plan
+    from libs import exporter
+    in_shape, pad_shape = (1, 192, 256, 3), (193, 257)
+    cfg = pipeline_pb2.PipelineConfig()
+    text_format.Merge(CFG % dict(arch='icnet', ext='dilated_resnet50', fs=1.0, pf=[1.0, 2.0, 3.0, 4.0],
+                                 h=pad_shape[0], w=pad_shape[1]), cfg)
+    cfg.model.icnet.pretrain_single_branch_mode = True
+    g = G.reset_default_graph()
+    _, model = model_builder.build(cfg.model, is_training=False)
+    _, inp = exporter._image_tensor_input_placeholder(in_shape, pad_shape)
+    logits = model.predict(model.preprocess(G.to_float(inp)))[model.main_class_predictions_key]
+    outs = [logits, G.argmax(logits, 3)]
+    weights = synth.make_weights(g.variables, seed=1234, input_std=70.0)
+    assert 'Conv/weights' not in weights and 'CascadeFeatureFusion/Conv/weights' not in weights
+    img = np.random.default_rng(5).integers(0, 256, in_shape).astype(np.uint8)
+    x = nets.preprocess(O.pad_to_bounding_box(img.astype(np.float32), *pad_shape), 'dilated_resnet50')
+    ref = nets.icnet_predict(nets.Params(weights), x, pretrain_single_branch_mode=True)
+    got, labels = plan.CompiledGraph(g, outs, weights, dtype=dtype).run(img)
+    assert got.shape == ref.shape == (1,) + pad_shape + (19,)
+    err = float(np.abs(got - ref).max()) / float(np.abs(ref).max())
+    agree = float((labels[..., 0] == O.argmax_channels(ref)).mean())
+    print('single-branch ICNet %s: logit err %.3g of scale, argmax agreement %.5f' % (dtype, err, agree))
+    assert err <= tol
+    if dtype != 'bfloat16':
+        assert agree >= 0.999
