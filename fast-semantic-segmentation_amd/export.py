@@ -94,11 +94,18 @@ def export_inference_graph(pipeline_config, trained_checkpoint_prefix, output_di
 
     # the inference variables, from a checkpoint prefix or another frozen graph
     weights = frozen_graph.load_weights(trained_checkpoint_prefix, graph.variables)
-    checkpoint.save_variables(model_path, weights)
+    layers = [nd for nd in graph.nodes if nd.kind in ('conv2d', 'depthwise')]
+    # a source with folded batch norm: the checkpoint (and the unfolded frozen graph) get
+    # statistics that reproduce the folded bias, so both load like a trained model's
+    plain = frozen_graph.unfold_batch_norm(
+        weights, [(nd.attrs['weights'].rsplit('/', 1)[0], nd.attrs['bn']) for nd in layers if nd.attrs['bn']])
+    checkpoint.save_variables(model_path, plain)
     checkpoint.write_checkpoint_state(output_directory, [model_path])
-    convs = [(nd.attrs['weights'].rsplit('/', 1)[0], nd.attrs['rate'] > 1)
-             for nd in graph.nodes if nd.kind == 'conv2d']
-    frozen_graph.save_frozen_graph(frozen_graph_path, weights, convs, fold_batch_norm=fold_batch_norm)
+    # every layer folds with its own batch norm epsilon, as the plan compiler does
+    convs = [(nd.attrs['weights'].rsplit('/', 1)[0], nd.attrs['rate'] > 1,
+              nd.attrs['bn']['epsilon'] if nd.attrs['bn'] else None, nd.kind == 'depthwise') for nd in layers]
+    frozen_graph.save_frozen_graph(frozen_graph_path, weights if fold_batch_norm else plain, convs,
+                                   fold_batch_norm=fold_batch_norm)
     print('Done!')
     return totals
 

@@ -215,37 +215,75 @@ def _node(name, op, inputs=(), tensor=None):
 
 def save_frozen_graph(path, variables, convs=(), fold_batch_norm=False, epsilon=1e-5):
     """Writes a GraphDef shaped like a frozen inference graph: one Const (+ Identity `read`) per
-    variable and, for every (scope, dilated) in `convs`, a Conv2D node reading `<scope>/weights`.
-    fold_batch_norm: the BatchNorm constants of those convolutions are folded into the weights
-    and a bias that a BiasAdd applies (behind a BatchToSpaceND when `dilated`)."""
+    variable and, for every entry of `convs`, a convolution node reading the scope's kernel.
+    An entry is (scope, dilated[, epsilon[, depthwise]]): `epsilon` is that layer's batch norm
+    epsilon (default: the `epsilon` argument), `depthwise` makes the node a
+    DepthwiseConv2dNative reading `<scope>/depthwise_weights`.
+    fold_batch_norm: the BatchNorm constants of those convolutions are folded into the kernels
+    and a bias that a BiasAdd applies (behind a BatchToSpaceND when `dilated`).  A scope whose
+    batch norm is folded already (`<scope>/folded_bias` among the variables, as load_variables
+    returns it) is written in that form whatever `fold_batch_norm` says: kernel untouched,
+    the vector behind a BiasAdd."""
     variables = dict(variables)
     out = b''
     extra = []
-    for scope, dilated in convs:
-        wname = scope + '/weights'
+    for entry in convs:
+        scope, dilated = entry[0], entry[1]
+        eps = entry[2] if len(entry) > 2 and entry[2] is not None else epsilon
+        depthwise = len(entry) > 3 and entry[3]
+        wname = scope + ('/depthwise_weights' if depthwise else '/weights')
+        op = 'DepthwiseConv2dNative' if depthwise else 'Conv2D'
         conv_in = 'input_of/' + scope
         extra.append(_node(conv_in, 'Placeholder'))
-        conv_node = scope + '/Conv2D'
-        tail = conv_node
-        if fold_batch_norm and scope + '/BatchNorm/moving_variance' in variables:
+        conv_node = scope + ('/depthwise' if depthwise else '/Conv2D')
+        bias = None
+        if scope + '/folded_bias' in variables:
+            bias = np.asarray(variables.pop(scope + '/folded_bias'), np.float32)
+        elif fold_batch_norm and scope + '/BatchNorm/moving_variance' in variables:
             g = variables.pop(scope + '/BatchNorm/gamma', None)
             b = variables.pop(scope + '/BatchNorm/beta', None)
             m = variables.pop(scope + '/BatchNorm/moving_mean')
             v = variables.pop(scope + '/BatchNorm/moving_variance')
-            s = 1.0 / np.sqrt(v.astype(np.float64) + epsilon)
+            sc = 1.0 / np.sqrt(v.astype(np.float64) + eps)
             if g is not None:
-                s = s * g
-            bias = -m * s + (b if b is not None else 0.0)
-            variables[wname] = (variables[wname].astype(np.float64) * s).astype(np.float32)
-            variables[scope + '/folded/bias_const'] = bias.astype(np.float32)
+                sc = sc * g
+            bias = (-m * sc + (b if b is not None else 0.0)).astype(np.float32)
+            w = variables[wname].astype(np.float64)
+            # depthwise kernels are [kh, kw, c, 1]: the scale runs along axis 2
+            variables[wname] = (w * (sc.reshape(-1, 1) if depthwise else sc)).astype(np.float32)
+        if bias is not None:
+            tail = conv_node
+            variables[scope + '/folded/bias_const'] = bias
             if dilated:
                 extra.append(_node(scope + '/BatchToSpaceND', 'BatchToSpaceND', [conv_node]))
                 tail = scope + '/BatchToSpaceND'
             extra.append(_node(scope + '/BiasAdd', 'BiasAdd', [tail, scope + '/folded/bias_const']))
-        extra.append(_node(conv_node, 'Conv2D', [conv_in, wname + '/read']))
+        extra.append(_node(conv_node, op, [conv_in, wname + '/read']))
     for name in sorted(variables):
         out += _node(name, 'Const', tensor=np.asarray(variables[name]))
         out += _node(name + '/read', 'Identity', [name])
     out += b''.join(extra)
     with open(path, 'wb') as f:
         f.write(out)
+
+
+def unfold_batch_norm(weights, bn_layers):
+    """Variables of the unfolded graph for weights whose batch norm is folded already: for every
+    (scope, bn) of `bn_layers` (bn = the layer's batch norm variable names and epsilon) that has
+    a `<scope>/folded_bias` in `weights`, BatchNorm statistics under which the layer computes
+    exactly conv + that vector - mean = -bias, variance = 1 - epsilon, gamma = 1, beta = 0 - take
+    the vector's place.  A checkpoint written from the result loads like any trained one."""
+    out = dict(weights)
+    for scope, bn in bn_layers:
+        key = scope + '/folded_bias'
+        if key not in out:
+            continue
+        bias = np.asarray(out.pop(key), np.float32)
+        # float32(1 - eps) + eps is 1 to a few 1e-8: the folded scale is 1 to float precision
+        out[bn['var']] = np.full(bias.shape, 1.0 - bn['epsilon'], np.float32)
+        out[bn['mean']] = -bias
+        if bn['gamma'] is not None:
+            out[bn['gamma']] = np.ones(bias.shape, np.float32)
+        if bn['beta'] is not None:
+            out[bn['beta']] = np.zeros(bias.shape, np.float32)
+    return out

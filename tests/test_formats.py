@@ -199,6 +199,31 @@ def test_frozen_graph_reader(tmp_path):
         np.testing.assert_allclose(got[scope + '/folded_bias'],
                                    v[scope + '/BatchNorm/beta'] - v[scope + '/BatchNorm/moving_mean'] * s, rtol=1e-5, atol=1e-6)
     np.testing.assert_array_equal(got['Predictions/Conv/biases'], v['Predictions/Conv/biases'])
+    # every layer folds with its own epsilon; depthwise kernels fold along their channel axis
+    v2 = dict(v)
+    v2['D/depthwise/depthwise_weights'] = rng.normal(0, 1, (3, 3, 8, 1)).astype(np.float32)
+    for leaf, lo, hi in (('beta', -1, 1), ('moving_mean', -1, 1), ('moving_variance', 0.5, 1.5)):
+        v2['D/depthwise/BatchNorm/' + leaf] = rng.uniform(lo, hi, 8).astype(np.float32)
+    convs2 = [('A/Conv', False, 1e-3), ('A/Dil', True, None), ('D/depthwise', False, 0.01, True)]
+    frozen_graph.save_frozen_graph(folded, v2, convs2, fold_batch_norm=True)
+    got = frozen_graph.load_variables(folded)
+    s = v['A/Conv/BatchNorm/gamma'] / np.sqrt(v['A/Conv/BatchNorm/moving_variance'].astype(np.float64) + 1e-3)
+    np.testing.assert_allclose(got['A/Conv/weights'], v['A/Conv/weights'] * s, rtol=1e-6)
+    s = 1.0 / np.sqrt(v2['D/depthwise/BatchNorm/moving_variance'].astype(np.float64) + 0.01)    # no gamma
+    np.testing.assert_allclose(got['D/depthwise/depthwise_weights'][..., 0],
+                               v2['D/depthwise/depthwise_weights'][..., 0] * s, rtol=1e-6)
+    np.testing.assert_allclose(got['D/depthwise/folded_bias'],
+                               v2['D/depthwise/BatchNorm/beta'] - v2['D/depthwise/BatchNorm/moving_mean'] * s,
+                               rtol=1e-5, atol=1e-6)
+    # a folded graph written again stays folded, bit for bit, whatever the flag says
+    again = str(tmp_path / 'again.pb')
+    frozen_graph.save_frozen_graph(again, got, convs2, fold_batch_norm=False)
+    got2 = frozen_graph.load_variables(again)
+    assert set(got2) == set(got)
+    for k in got:
+        np.testing.assert_array_equal(got2[k], got[k])
+    ops = {n['name']: n['op'] for n in frozen_graph.parse_graph_def(open(again, 'rb').read())}
+    assert ops['D/depthwise/depthwise'] == 'DepthwiseConv2dNative' and ops['D/depthwise/BiasAdd'] == 'BiasAdd'
 
 
 def test_export_cli_writes_inference_checkpoint_and_frozen_graph(tmp_path):
@@ -255,6 +280,28 @@ def test_export_cli_writes_inference_checkpoint_and_frozen_graph(tmp_path):
     scope = 'CascadeFeatureFusion/DilatedConv'
     s = weights[scope + '/BatchNorm/gamma'] / np.sqrt(weights[scope + '/BatchNorm/moving_variance'].astype(np.float64) + 1e-5)
     np.testing.assert_allclose(folded[scope + '/weights'], weights[scope + '/weights'] * s, rtol=1e-6)
+    # round trip from the folded graph: its export is a checkpoint (and a plain frozen graph) that
+    # load like a trained model's, with batch norm statistics that give the folded bias back ...
+    out3 = str(tmp_path / 'export_from_folded')
+    export.main(['--config_path', cfg_path, '--trained_checkpoint', os.path.join(out2, 'frozen_inference_graph.pb'),
+                 '--output_dir', out3, '--input_shape', '1024,2048,3', '--pad_to_shape', '1025,2049'])
+    for src3 in (os.path.join(out3, 'model.ckpt'), os.path.join(out3, 'frozen_inference_graph.pb')):
+        back = frozen_graph.load_weights(src3, g.variables)
+        assert set(back) == set(weights)
+        np.testing.assert_array_equal(back[scope + '/weights'], folded[scope + '/weights'])
+        sc = back[scope + '/BatchNorm/gamma'] / np.sqrt(back[scope + '/BatchNorm/moving_variance'].astype(np.float64) + 1e-5)
+        np.testing.assert_allclose(sc, 1.0, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(back[scope + '/BatchNorm/beta'] - back[scope + '/BatchNorm/moving_mean'] * sc,
+                                   folded[scope + '/folded_bias'], rtol=1e-6, atol=1e-7)
+    # ... and folding a folded graph again changes nothing
+    out4 = str(tmp_path / 'export_folded_twice')
+    export.main(['--config_path', cfg_path, '--trained_checkpoint', os.path.join(out2, 'frozen_inference_graph.pb'),
+                 '--output_dir', out4, '--input_shape', '1024,2048,3', '--pad_to_shape', '1025,2049',
+                 '--fold_batch_norm'])
+    twice = frozen_graph.load_weights(os.path.join(out4, 'frozen_inference_graph.pb'), g.variables)
+    assert set(twice) == set(folded)
+    for k in folded:
+        np.testing.assert_array_equal(twice[k], folded[k])
 
 
 def test_create_cityscapes_tfrecord_tool(tmp_path):
