@@ -17,7 +17,7 @@ import numpy as np
 
 CASES = {
     # name: (config file, input shape, pad shape, batches)
-    'icnet10': ('single_stage_icnet_1.0_1025_resnet_v1.config', (1024, 2048, 3), (1025, 2049), (1, 16, 32, 64, 128)),
+    'icnet10': ('single_stage_icnet_1.0_1025_resnet_v1.config', (1024, 2048, 3), (1025, 2049), (1, 16, 32, 64, 128, 192)),
     'pspnet713': ('pspnet_1.0_713_resnet_v1.config', (713, 713, 3), (713, 713), (1, 8, 16)),
     'icnet05': ('two_stage_icnet_0.5_1025_resnet_v1_stage_2.config', (1024, 2048, 3), (1025, 2049), (1, 32, 64)),
     'icnet_mnv2': ('single_stage_icnet_1.0_1025_mobilenet_v2.config', (1024, 2048, 3), (1025, 2049), (1, 16, 64)),
