@@ -53,6 +53,15 @@ _ESZ = {'f32': 4, 'f32s': 4, 'bf16': 2, 'f16': 2, 'u8': 1}
 # convolutions that read or write it and the whole head stay float with split-bf16 products:
 # half precision there costs two to three times as many labels for a fifth of the time saved.
 DEFAULT_HALF_SCOPES = (r'/bottleneck_v1/conv2$', r'^Conv(_[123])?$')
+# 1x1 convolutions that the 'mixed' mode feeds with half-precision ACTIVATIONS while their weights
+# keep float quality (two f16 numbers per weight, two MFMAs per product instead of three): the last
+# convolution of a bottleneck unit (conv3, third_party/dilated_resnet_v1.py:98-100), whose input is
+# the half-precision convolution before it.  Rounding an activation to 11 bits is an independent
+# error per element that averages out over the K axis; rounding a weight is the same error for
+# every pixel.  On the float32 oracle, 11-bit activations in every conv3 raise the rms logit error
+# of the mode from 1.82e-4 to 1.93e-4 of the logit rms (tools/precision_emulation.py style run),
+# where 11-bit weights in the same layers cost several times that.
+DEFAULT_HALF_ACT_SCOPES = (r'/bottleneck_v1/conv3$',)
 
 
 def f32_to_bf16_bits(a):
@@ -170,7 +179,7 @@ class CompiledGraph(object):
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
                  fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True, fuse_chain=True, commute_pyramid=None, resident_3x3=True,
                  fuse_head=True, collapse_zooms=True, commute_zoom=None, fuse_zoom_residual=None,
-                 ksplit=False, half_scopes=None):
+                 ksplit=False, half_scopes=None, half_act_scopes=None):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         # 'float32x3': float32 tensors everywhere; the convolutions form their products on the
@@ -186,6 +195,11 @@ class CompiledGraph(object):
                    'float32x3': 'f32s', 'f32x3': 'f32s', 'mixed': 'f32s'}[dtype]
         import re
         self.half_re = [re.compile(p) for p in (DEFAULT_HALF_SCOPES if half_scopes is None else half_scopes)]
+        # `half_act_scopes` (DEFAULT_HALF_ACT_SCOPES): 1x1 convolutions that read half-precision
+        # activations with float-quality weights, so that the tensor in front of them is stored in
+        # half precision too
+        self.half_act_re = [re.compile(p) for p in
+                            (DEFAULT_HALF_ACT_SCOPES if half_act_scopes is None else half_act_scopes)]
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
         self.weights = weights
         self.outputs = list(outputs)
@@ -333,6 +347,29 @@ class CompiledGraph(object):
         scope = ln.attrs['weights'].rsplit('/', 1)[0]
         return any(r.search(scope) for r in self.half_re)
 
+    def _takes_half_acts(self, ln):
+        """Mixed mode: `ln` is a 1x1 convolution that reads half-precision activations against
+        weights kept as two f16 numbers each (emitted as a two-input launch whose second input is
+        the first one again and whose second filter holds the weights' remainders)."""
+        if not self.mixed or ln.kind != 'conv2d' or self._is_half_conv(ln):
+            return False
+        a = ln.attrs
+        scope = a['weights'].rsplit('/', 1)[0]
+        if not any(r.search(scope) for r in self.half_act_re):
+            return False
+        if ((a['kh'], a['kw'], a['stride'], a['rate'], a['pad_top'], a['pad_left']) != (1, 1, 1, 1, 0, 0)
+                or a['biases'] is not None or ln.inputs[0].shape[3] % 64 or ln.shape[:3] != ln.inputs[0].shape[:3]):
+            return False
+        if not self.fuse_dual:
+            return True
+        # not when it shares a launch with a projection shortcut (whose input is not half precision)
+        add = self._only_consumer(ln, 'add')
+        if add is not None:
+            for other in add.inputs:
+                if other is not ln and other.kind == 'conv2d' and self._dual_partner(other) is ln:
+                    return False
+        return ln not in self.dual and self._dual_partner(ln) is None
+
     def _store_dt(self, result, in_dt):
         """Storage type of the tensor `result` a convolution reading `in_dt` tensors produces.
         Outside the mixed mode: the input's.  Mixed mode: half precision when every consumer is a
@@ -342,7 +379,7 @@ class CompiledGraph(object):
         if result.is_output or not result.consumers:
             return self.dt
         for c in result.consumers:
-            if c.kind == 'conv2d' and c.inputs[0] is result and self._is_half_conv(c):
+            if c.kind == 'conv2d' and c.inputs[0] is result and (self._is_half_conv(c) or self._takes_half_acts(c)):
                 continue
             if c.kind == 'add' and len(c.inputs) == 2:
                 # a residual: the half-precision convolution that absorbs the add reads it in the
@@ -1051,6 +1088,30 @@ class CompiledGraph(object):
                         self.sh),
                        flops=2 * n * ho * wo * cout * 9 * cin,
                        nbytes=(n * h * w * cin + n * ho * wo * cout + cout * 9 * cin) * 2)
+            return
+        if in_dt == 'f16' and pc == cin and self._takes_half_acts(ln):
+            # half-precision activations, float-quality weights: W = hi + lo with hi = f16(W),
+            # lo = f16(W - hi), as the two filters of a two-input launch that reads x twice
+            hi = f32_to_f16_bits(Wp[:, :cin]).view(np.float16).astype(np.float32)
+            k_pad2 = (2 * cin + 63) // 64 * 64
+            W2 = np.zeros((cout_pad, k_pad2), np.float32)
+            W2[:, :cin] = hi
+            W2[:, cin:2 * cin] = Wp[:, :cin] - hi
+            wdev = self._pack(W2, 'f16')
+            out = Val(self._alloc(ln.shape, out_dt), ln.shape, out_dt)
+            self.vals[result] = out
+            if result is not ln:
+                self.vals[ln] = out
+            d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=1, kw=1, stride=1, dilation=1, pad_top=0,
+                              pad_left=0, ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE['f16'],
+                              out_dtype=_CODE[out_dt], y_ld=out.ld, res_ld=res.ld if res else 0,
+                              k_pad=k_pad2, cout_pad=cout_pad)
+            nbytes = ((n * h * w * cin + 2 * cout * cin) * 2 + n * ho * wo * cout * _ESZ[out_dt]
+                      + (n * ho * wo * cout * _ESZ[res.dt] if res else 0))
+            self._emit('conv', a['weights'].rsplit('/', 1)[0], 'fss_conv2d_dual_nhwc',
+                       (ctypes.byref(d), x.ptr, x.ptr, cin, wdev.data_ptr(), bdev.data_ptr(),
+                        res.ptr if res else None, out.ptr, self.sh),
+                       flops=2 * n * ho * wo * cout * cin, nbytes=nbytes, keep=d, mpp=2)
             return
         head = None
         if res is None and a['biases'] is None and pc == cin and cin % 64 == 0 and a['stride'] == 1:
