@@ -198,6 +198,8 @@ class CompiledGraph(object):
         # `half_act_scopes` (DEFAULT_HALF_ACT_SCOPES): 1x1 convolutions that read half-precision
         # activations with float-quality weights, so that the tensor in front of them is stored in
         # half precision too
+        if half_act_scopes is None and 'FSS_HALF_ACT_SCOPES' in os.environ:      # experiments: '' = none
+            half_act_scopes = [p for p in os.environ['FSS_HALF_ACT_SCOPES'].split(',') if p]
         self.half_act_re = [re.compile(p) for p in
                             (DEFAULT_HALF_ACT_SCOPES if half_act_scopes is None else half_act_scopes)]
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
