@@ -43,37 +43,50 @@ constexpr int kStemRows = 6;
 
 template <typename T> struct StemPix;      // one preprocessed pixel in LDS: 4 x T
 template <> struct StemPix<bf16_t> {
-  static __device__ __forceinline__ void store(char* p, float a, float b, float c) {
+  static __device__ __forceinline__ void store(char* p, float a, float b, float c, float d) {
     uint2 o;
     o.x = pack_bf16x2(a, b);
-    o.y = pack_bf16x2(c, 0.f);
+    o.y = pack_bf16x2(c, d);
+    *reinterpret_cast<uint2*>(p) = o;
+  }
+};
+template <> struct StemPix<f16_t> {
+  static __device__ __forceinline__ void store(char* p, float a, float b, float c, float d) {
+    uint2 o;
+    o.x = pack_f16x2(a, b);
+    o.y = pack_f16x2(c, d);
     *reinterpret_cast<uint2*>(p) = o;
   }
 };
 template <> struct StemPix<float> {
-  static __device__ __forceinline__ void store(char* p, float a, float b, float c) {
-    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, 0.f);
+  static __device__ __forceinline__ void store(char* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
   }
 };
 
 // NJ = 16-channel groups of output channels (cout_pad = 16 * NJ); KS = MFMA k steps of the
 // filter when known at compile time (bf16: 7 for 7x7, 2 for 3x3; the tap walk is then
 // unrolled with its patch offsets in registers), 0 = any filter
-// SPLIT (T = bf16_t, TO = float): the float-quality form.  The preprocessed patch is kept as two
-// bf16 images (high parts, remainders), the weights arrive as two bf16 matrices (high parts
-// [cout_pad][k_pad], then remainders), and every MFMA step runs three times (lo*hi, hi*lo,
-// hi*hi) into the same float accumulators; the output is a split-bfloat16 tensor (f32s_t).
+// SPLIT (T = f16_t, TO = f32s_t): the float-quality form.  The patch holds the RAW frame bytes
+// as half-precision numbers (exact) and, in channel 3, a 1 wherever the pixel lies inside the
+// padded image; mean and scale live in the weights, which the caller packs as
+//   W'[co][4 tap + c] = W[tap][c][co] * scale[c],  W'[co][4 tap + 3] = -sum_c W[tap][c][co] * mean[c] * scale[c]
+// and hands over as two f16 matrices (high parts [cout_pad][k_pad], then remainders): conv(x) with
+// x = (u - mean) * scale inside the image and 0 on the convolution's own padding is linear in
+// (u, 1), so nothing of the activation operand is ever rounded, and a product costs two MFMAs
+// (lo, hi) instead of the three of a two-sided split.  The output is a split-bfloat16 tensor.
 template <typename T, int NJ, int KS, typename TO = T, bool SPLIT = false>
 __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   constexpr int ES = (int)sizeof(T);
-  static_assert(!SPLIT || (sizeof(T) == 2 && sizeof(TO) == 4), "split mode: bf16 operands, float output");
+  static_assert(!SPLIT || (std::is_same<T, f16_t>::value && sizeof(TO) == 4),
+                "float-quality mode: f16 operands, split-bfloat16 output");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* tapoff = reinterpret_cast<int*>(smem);            // 64 patch offsets (in pixels)
   const int WROW = a.K4pad * ES + 16;                    // +16: rows land on distinct banks
   char* wl = smem + 256;
   char* patch = wl + (SPLIT ? 2 : 1) * NJ * 16 * WROW;
-  // split mode: remainders of the weights behind the high parts, of the patch behind the patch
-  const int WLO = NJ * 16 * WROW, PLO = a.PH * a.PW * 4 * ES;
+  // float-quality mode: the remainders of the weights lie behind their high parts
+  const int WLO = NJ * 16 * WROW;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -195,15 +208,10 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
       u[k] = *reinterpret_cast<const unsigned*>(frame + off4) >> ((off - off4) * 8u);
     }
   };
-  // one preprocessed pixel into the patch (split mode: its bf16 high parts and remainders)
-  auto store_pix = [&](int pix, const float (&v)[3]) {
-    char* dst = patch + (size_t)pix * (4 * ES);
-    StemPix<T>::store(dst, v[0], v[1], v[2]);
-    if constexpr (SPLIT) {
-      const uint2 hi = *reinterpret_cast<const uint2*>(dst);
-      StemPix<T>::store(dst + PLO, v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u),
-                        v[2] - __uint_as_float(hi.y << 16));
-    }
+  // one pixel into the patch: its three preprocessed channels (float-quality mode: its raw
+  // bytes) and `one` in channel 3 (0, or in the float-quality mode 1 inside the padded image)
+  auto store_pix = [&](int pix, const float (&v)[3], float one) {
+    StemPix<T>::store(patch + (size_t)pix * (4 * ES), v[0], v[1], v[2], one);
   };
   // zero padding of the frame, mean / scale, rounding; stores the patch into LDS
   auto commit = [&](const Tile& t, const unsigned (&u)[kStemRows]) {
@@ -216,10 +224,13 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
           float v[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            v[c] = (float)((u[k] >> (8 * c)) & 255u) - a.mean[c];
-            if (!a.unit_scale) v[c] *= a.scale[c];
+            v[c] = (float)((u[k] >> (8 * c)) & 255u);
+            if constexpr (!SPLIT) {
+              v[c] -= a.mean[c];
+              if (!a.unit_scale) v[c] *= a.scale[c];
+            }
           }
-          if (lane < a.PW) store_pix(pi * a.PW + lane, v);
+          if (lane < a.PW) store_pix(pi * a.PW + lane, v, SPLIT ? 1.f : 0.f);
         }
       }
       return;
@@ -236,11 +247,15 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
         float v[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          v[c] = fmaf((float)((u[k] >> (8 * c)) & 255u), m_real, -a.mean[c]);    // exact: (u or 0) - mean
-          if (!a.unit_scale) v[c] *= a.scale[c];
+          if constexpr (SPLIT) {
+            v[c] = (float)((u[k] >> (8 * c)) & 255u) * m_real;                     // u, or 0 on the frame's padding
+          } else {
+            v[c] = fmaf((float)((u[k] >> (8 * c)) & 255u), m_real, -a.mean[c]);    // exact: (u or 0) - mean
+            if (!a.unit_scale) v[c] *= a.scale[c];
+          }
           v[c] = inside ? v[c] : 0.f;
         }
-        if (lane < a.PW) store_pix(pi * a.PW + lane, v);
+        if (lane < a.PW) store_pix(pi * a.PW + lane, v, SPLIT && inside ? 1.f : 0.f);
       }
     }
   };
@@ -291,21 +306,11 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
           const uint2 b1 = *reinterpret_cast<const uint2*>(patch + (bo[mt] + to.y * 8));
           const uint4 b = make_uint4(b0.x, b0.y, b1.x, b1.y);
           if constexpr (SPLIT) {
-            const uint2 c0 = *reinterpret_cast<const uint2*>(patch + PLO + (bo[mt] + to.x * 8));
-            const uint2 c1 = *reinterpret_cast<const uint2*>(patch + PLO + (bo[mt] + to.y * 8));
-            const uint4 bl = make_uint4(c0.x, c0.y, c1.x, c1.y);
 #pragma unroll
-            for (int nj = 0; nj < NJ; ++nj) {
-              acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8_t, wlo[nj]), __builtin_bit_cast(bf16x8_t, b), acc[mt][nj], 0, 0, 0);
-              acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8_t, wa[nj]), __builtin_bit_cast(bf16x8_t, bl), acc[mt][nj], 0, 0, 0);
-            }
+            for (int nj = 0; nj < NJ; ++nj) acc[mt][nj] = mfma_16x16x32<T>(wlo[nj], b, acc[mt][nj]);
           }
 #pragma unroll
-          for (int nj = 0; nj < NJ; ++nj)
-            acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8_t, wa[nj]), __builtin_bit_cast(bf16x8_t, b), acc[mt][nj], 0, 0, 0);
+          for (int nj = 0; nj < NJ; ++nj) acc[mt][nj] = mfma_16x16x32<T>(wa[nj], b, acc[mt][nj]);
         }
       }
     } else if constexpr (sizeof(T) == 2) {
@@ -328,21 +333,11 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
           const uint2 b1 = *reinterpret_cast<const uint2*>(patch + (size_t)(base[mt] + to.y) * 8);
           const uint4 b = make_uint4(b0.x, b0.y, b1.x, b1.y);
           if constexpr (SPLIT) {
-            const uint2 c0 = *reinterpret_cast<const uint2*>(patch + PLO + (size_t)(base[mt] + to.x) * 8);
-            const uint2 c1 = *reinterpret_cast<const uint2*>(patch + PLO + (size_t)(base[mt] + to.y) * 8);
-            const uint4 bl = make_uint4(c0.x, c0.y, c1.x, c1.y);
 #pragma unroll
-            for (int nj = 0; nj < NJ; ++nj) {
-              acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8_t, wlo[nj]), __builtin_bit_cast(bf16x8_t, b), acc[mt][nj], 0, 0, 0);
-              acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  __builtin_bit_cast(bf16x8_t, wa[nj]), __builtin_bit_cast(bf16x8_t, bl), acc[mt][nj], 0, 0, 0);
-            }
+            for (int nj = 0; nj < NJ; ++nj) acc[mt][nj] = mfma_16x16x32<T>(wlo[nj], b, acc[mt][nj]);
           }
 #pragma unroll
-          for (int nj = 0; nj < NJ; ++nj)
-            acc[mt][nj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8_t, wa[nj]), __builtin_bit_cast(bf16x8_t, b), acc[mt][nj], 0, 0, 0);
+          for (int nj = 0; nj < NJ; ++nj) acc[mt][nj] = mfma_16x16x32<T>(wa[nj], b, acc[mt][nj]);
         }
       }
     } else {
@@ -523,8 +518,8 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
   a.total_tiles = (int)total;
   for (int i = 0; i < 3; ++i) { a.mean[i] = mean3[i]; a.scale[i] = scale3[i]; }
   a.unit_scale = scale3[0] == 1.f && scale3[1] == 1.f && scale3[2] == 1.f;
-  const int es = dtype == FSS_F32 ? 4 : 2, planes = dtype == FSS_F32_BF16X3 ? 2 : 1;
-  const size_t smem = 256 + planes * ((size_t)cout_pad * (k_pad * es + 16) + (size_t)a.PH * a.PW * 4 * es);
+  const int es = dtype == FSS_F32 ? 4 : 2, wplanes = dtype == FSS_F32_BF16X3 ? 2 : 1;
+  const size_t smem = 256 + wplanes * (size_t)cout_pad * (k_pad * es + 16) + (size_t)a.PH * a.PW * 4 * es;
   FSS_REQUIRE(smem <= 160 * 1024, "filter too large for LDS");
   hipStream_t s = (hipStream_t)stream;
   const int nj = cout_pad / 16;
@@ -537,14 +532,14 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
   }
   if (dtype == FSS_F32) { FSS_STEM(float) }
   if (dtype == FSS_F32_BF16X3) {
-    if (nj == 4 && k_pad == 224) return launch_stem<bf16_t, 4, 7, f32s_t, true>(a, smem, s);
-    if (nj == 2 && k_pad == 64) return launch_stem<bf16_t, 2, 2, f32s_t, true>(a, smem, s);
-    if (nj == 4 && k_pad == 64) return launch_stem<bf16_t, 4, 2, f32s_t, true>(a, smem, s);
+    if (nj == 4 && k_pad == 224) return launch_stem<f16_t, 4, 7, f32s_t, true>(a, smem, s);
+    if (nj == 2 && k_pad == 64) return launch_stem<f16_t, 2, 2, f32s_t, true>(a, smem, s);
+    if (nj == 4 && k_pad == 64) return launch_stem<f16_t, 4, 2, f32s_t, true>(a, smem, s);
     switch (nj) {
-      case 1: return launch_stem<bf16_t, 1, 0, f32s_t, true>(a, smem, s);
-      case 2: return launch_stem<bf16_t, 2, 0, f32s_t, true>(a, smem, s);
-      case 3: return launch_stem<bf16_t, 3, 0, f32s_t, true>(a, smem, s);
-      default: return launch_stem<bf16_t, 4, 0, f32s_t, true>(a, smem, s);
+      case 1: return launch_stem<f16_t, 1, 0, f32s_t, true>(a, smem, s);
+      case 2: return launch_stem<f16_t, 2, 0, f32s_t, true>(a, smem, s);
+      case 3: return launch_stem<f16_t, 3, 0, f32s_t, true>(a, smem, s);
+      default: return launch_stem<f16_t, 4, 0, f32s_t, true>(a, smem, s);
     }
   }
   // the two filters of the reference's networks: unrolled tap walk

@@ -77,6 +77,24 @@ def f32_to_f16_bits(a):
     return a.astype(np.float16).view(np.uint16)
 
 
+def stem_pack_f16x2(W, mean, scale, cout_pad, k_pad):
+    """Weights of fss_stem_conv_u8 in its FSS_F32_BF16X3 mode from the filter W [kh,kw,3,cout]
+    (batch norm folded in): the kernel multiplies the raw frame bytes and a 1 per pixel inside the
+    padded image, so scale goes into the three channel weights and -sum_c W_c mean_c scale_c into
+    the fourth; returned as uint16 [2 * cout_pad][k_pad]: IEEE-half high parts, then remainders."""
+    kh, kw, _, cout = W.shape
+    W = np.asarray(W, np.float64)
+    ms = np.asarray(mean, np.float64) * np.asarray(scale, np.float64)
+    W4 = np.zeros((kh, kw, 4, cout))
+    W4[:, :, :3] = W * np.asarray(scale, np.float64)[None, None, :, None]
+    W4[:, :, 3] = -(W * ms[None, None, :, None]).sum(axis=2)
+    Wp = np.zeros((cout_pad, k_pad))
+    Wp[:cout, :kh * kw * 4] = W4.transpose(3, 0, 1, 2).reshape(cout, -1)
+    hi = f32_to_f16_bits(Wp.astype(np.float32))
+    lo = f32_to_f16_bits((Wp - hi.view(np.float16).astype(np.float64)).astype(np.float32))
+    return np.concatenate([hi, lo])
+
+
 def split_bf16_decode(raw):
     """float32 ndarray holding split-bfloat16 groups along its last axis (a multiple of 8 slots:
     8 bf16 high parts, then 8 bf16 remainders, per 8 elements) -> the float32 values."""
@@ -555,10 +573,8 @@ class CompiledGraph(object):
         elif self.dt == 'bf16':
             wdev = self._pack(Wp, 'bf16')
         elif self.split:
-            # two bf16 matrices: high parts, then remainders
-            hi = f32_to_bf16_bits(Wp)
-            lo = f32_to_bf16_bits(Wp - (hi.astype(np.uint32) << 16).view(np.float32))
-            wdev = torch.from_numpy(np.concatenate([hi, lo]).view(np.int16)).to(self.device)
+            wdev = torch.from_numpy(stem_pack_f16x2(Wt[:, :, :3], pre.attrs['mean'], pre.attrs['scale'],
+                                                    cout_pad.value, k_pad.value).view(np.int16)).to(self.device)
             self.keepalive.append(wdev)
         else:
             wdev = self._pack(Wp, 'f32')
@@ -576,7 +592,7 @@ class CompiledGraph(object):
                     _lib.ACT_CODES[a['activation']], code, out.ld, self.sh),
                    flops=2 * n * ho * wo * cout * kh * kw * 3,
                    nbytes=n * (hr // sub) * (wr // sub) * 3 + n * ho * wo * cout * _ESZ[self.dt],
-                   keep=(mean, sc), mpp=3 if code == _lib.F32_BF16X3 else 1)
+                   keep=(mean, sc), mpp=2 if code == _lib.F32_BF16X3 else 1)
 
     def _stem2_partner(self, ln):
         """(the convolution that consumes stem conv `ln`, the 16-bit type) when both can run as

@@ -358,9 +358,12 @@ int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho,
  * third_party/mobilenet_v2.py first conv).  Weights: [cout_pad][k_pad] with
  * k = (r*kw + s)*4 + ch (ch 3 = 0), dims from fss_stem_pack_dims, batch norm
  * folded in.  dtype FSS_F32_BF16X3: split-bfloat16 output (cout and y_ld multiples of 8) of
- * float quality from three bf16 MFMAs per step; the packed weights are two bf16 matrices
- * [cout_pad][k_pad], the high parts bf16(W) followed by the remainders bf16(W - high), dims
- * from fss_stem_pack_dims with that dtype.
+ * float quality.  The kernel then multiplies the RAW frame bytes (exact in half precision) and,
+ * as channel 3, a 1 for every pixel inside the h x w image; the caller folds mean and scale into
+ * the weights - W'[.][4 tap + c] = W[tap][c] * scale[c], W'[.][4 tap + 3] = -sum_c W[tap][c] *
+ * mean[c] * scale[c] - and packs them as two IEEE-half matrices [cout_pad][k_pad], the high parts
+ * f16(W') followed by the remainders f16(W' - high) (dims from fss_stem_pack_dims with that
+ * dtype); mean3 / scale3 are not used.  No activation is rounded and a product costs two MFMAs.
  * Limits: cout <= 64, kh*kw <= 64, stride, dilation <= 4. */
 int fss_stem_pack_dims(int kh, int kw, int cout, int dtype, int* k_pad, int* cout_pad);
 int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const float* bias, void* y,

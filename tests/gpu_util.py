@@ -287,21 +287,21 @@ def zoomed_dilated_conv(x, w, dt='f32'):
     return to_host(r, dt)
 
 
-def pack_stem_weights(w, dt):
-    """[kh,kw,3,cout] -> device [cout_pad][k_pad], k = tap*4 + channel."""
+def pack_stem_weights(w, dt, mean=None, scale=None):
+    """[kh,kw,3,cout] -> device [cout_pad][k_pad], k = tap*4 + channel ('f32x3': the two f16
+    matrices of the raw-byte form, with `mean` and `scale` folded in)."""
     kh, kw, cin, cout = w.shape
     assert cin == 3
     k_pad, cout_pad = ctypes.c_int(0), ctypes.c_int(0)
     _lib.call('fss_stem_pack_dims', kh, kw, cout, conv_in_code(dt), ctypes.byref(k_pad), ctypes.byref(cout_pad))
+    if dt == 'f32x3':
+        from fss import plan
+        return torch.from_numpy(plan.stem_pack_f16x2(w, mean, scale, cout_pad.value, k_pad.value).view(np.int16)).cuda()
     wp = np.zeros((cout_pad.value, k_pad.value), np.float32)
     w4 = np.pad(w, ((0, 0), (0, 0), (0, 1), (0, 0)))
     wp[:cout, :kh * kw * 4] = w4.transpose(3, 0, 1, 2).reshape(cout, -1)
     if dt in ('bf16', 'f16'):
         return torch.from_numpy(half_bits(wp, dt).view(np.int16)).cuda()
-    if dt == 'f32x3':       # high parts, then remainders
-        hi = f32_to_bf16_bits(wp)
-        lo = f32_to_bf16_bits(wp - (hi.astype(np.uint32) << 16).view(np.float32))
-        return torch.from_numpy(np.concatenate([hi, lo]).view(np.int16)).cuda()
     return torch.from_numpy(wp).cuda()
 
 
@@ -312,7 +312,7 @@ def stem_conv(frames, w, bias, mean, scale, sub, logical_hw, stride, rate, pads,
     kh, kw, _, cout = w.shape
     ho, wo = out_hw
     xd = torch.from_numpy(frames).cuda()
-    wdev = pack_stem_weights(w, dt)
+    wdev = pack_stem_weights(w, dt, mean, scale)
     bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda()
     ld = y_ld or cout
     y = torch.full((n, ho, wo, ld), -77.0, dtype=DT[dt][1], device='cuda')

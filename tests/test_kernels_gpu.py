@@ -576,7 +576,8 @@ def test_stem_conv_u8_matches_preprocess_resize_conv(case, dt):
     assert ref.shape[1:3] == (ho, wo)
     got = gu.stem_conv(frames, w, bias, mean, scale, sub, (hl, wl), stride, rate, (pads[0], pads[2]),
                        (ho, wo), act, dt, y_ld=y_ld)
-    _close(got, ref, 2e-4 if dt != 'bf16' else 1.0 / 128, 'stem conv %s' % dt)
+    # f32x3: raw bytes against two-f16 weights, nothing rounded but the split-bfloat16 store
+    _close(got, ref, {'bf16': 1.0 / 128, 'f32x3': 2e-5}.get(dt, 2e-4), 'stem conv %s' % dt)
 
 
 STEM2_CASES = [

@@ -61,7 +61,7 @@ def main():
             continue
         sub, (h, w), k, stride, pad, cout, (ho, wo) = SHAPES[name]
         wt = np.random.default_rng(0).normal(0, 0.05, (k, k, 3, cout)).astype(np.float32)
-        wdev = gu.pack_stem_weights(wt, args.dtype)
+        wdev = gu.pack_stem_weights(wt, args.dtype, (123.68, 116.779, 103.939), (1.0, 1.0, 1.0))
         bias = torch.randn(cout, device='cuda')
         y = torch.empty((n, ho, wo, cout), device='cuda', dtype=tdt)
         m3 = (ctypes.c_float * 3)(123.68, 116.779, 103.939)
