@@ -64,6 +64,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 // IEEE half precision: the compiler's own type as the storage tag (distinct from bf16_t for the
 // template machinery; two bytes).  Conversions round to nearest even (v_cvt_pk_f16_f32).
 typedef _Float16 f16_t;
+// Tag of the convolution mode FSS_F16_W2: half-precision activations (stored as f16_t) against
+// weights kept as two f16 numbers each.  Never the type of a tensor.
+struct f16w_t { _Float16 v; };
 typedef _Float16 fss_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
   fss_f32x2 f = {lo, hi};
@@ -261,6 +264,10 @@ template <> struct Chunk<f16_t> {
       v[2 * i] = Half16<f16_t>::lo(w[i]);
       v[2 * i + 1] = Half16<f16_t>::hi(w[i]);
     }
+  }
+  __device__ __forceinline__ void store_nt(f16_t* p) const {
+    typedef Half16<f16_t> H;
+    store16_nt(p, H::pack2(v[0], v[1]), H::pack2(v[2], v[3]), H::pack2(v[4], v[5]), H::pack2(v[6], v[7]));
   }
 };
 // bytes of a channel chunk of T (what the copy kernels move per thread)

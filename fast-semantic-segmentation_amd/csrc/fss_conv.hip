@@ -47,7 +47,9 @@ using namespace fss;
 extern "C" int fss_conv_pack_dims(int cin, int kh, int kw, int cout, int dtype, int* k_pad,
                                   int* cout_pad) {
   FSS_REQUIRE(k_pad && cout_pad, "null argument");
-  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F16 || dtype == FSS_F32_BF16X3, "bad dtype");
+  // (FSS_F16_W2: the dimensions of FSS_F16; the packed rows then hold 2 * k_pad elements)
+  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F16 || dtype == FSS_F32_BF16X3 ||
+                  dtype == FSS_F16_W2, "bad dtype");
   FSS_REQUIRE(cin > 0 && kh > 0 && kw > 0 && cout > 0, "bad shape");
   const int k = cin * kh * kw;
   *k_pad = (k + 63) / 64 * 64;          // a multiple of every K tile in use
@@ -85,22 +87,25 @@ static int conv_setup(const fss_conv_desc* d, const void* x, const void* x2, int
                       ConvArgs& a) {
   FSS_REQUIRE(d && x && w_packed && y, "null argument");
   FSS_REQUIRE(d->in_dtype == FSS_F32 || d->in_dtype == FSS_BF16 || d->in_dtype == FSS_F32_BF16X3 ||
-                  d->in_dtype == FSS_F16, "bad in_dtype");
+                  d->in_dtype == FSS_F16 || d->in_dtype == FSS_F16_W2, "bad in_dtype");
   FSS_REQUIRE(d->out_dtype == FSS_F32 || d->out_dtype == FSS_BF16 || d->out_dtype == FSS_F16 ||
                   d->out_dtype == FSS_F32_BF16X3, "bad out_dtype");
   FSS_REQUIRE(!(d->in_dtype != FSS_BF16 && d->out_dtype == FSS_BF16),
               "bf16 output needs bf16 input");
-  FSS_REQUIRE(!((d->out_dtype == FSS_F16 || d->out_dtype == FSS_F32_BF16X3) && d->in_dtype != FSS_F16 &&
+  const bool f16_in = d->in_dtype == FSS_F16 || d->in_dtype == FSS_F16_W2;
+  FSS_REQUIRE(!((d->out_dtype == FSS_F16 || d->out_dtype == FSS_F32_BF16X3) && !f16_in &&
                 d->in_dtype != FSS_F32_BF16X3),
               "f16 and split-bf16 outputs need f16 or FSS_F32_BF16X3 input");
-  const bool half_in = d->in_dtype == FSS_BF16 || d->in_dtype == FSS_F16;
+  FSS_REQUIRE(d->in_dtype != FSS_F16_W2 || d->out_dtype == FSS_F16 || d->out_dtype == FSS_F32_BF16X3,
+              "FSS_F16_W2 stores FSS_F16 or FSS_F32_BF16X3");
+  const bool half_in = d->in_dtype == FSS_BF16 || f16_in;
   // channels per addressable group of the input (16 bytes; 32 for split-bf16 tensors)
   const int epc = half_in || d->in_dtype == FSS_F32_BF16X3 ? 8 : 4;
   const int esz = half_in ? 2 : 4;
   if (d->out_dtype == FSS_F32_BF16X3)
     FSS_REQUIRE(d->cout % 8 == 0 && d->y_ld % 8 == 0 && ((uintptr_t)y & 31) == 0,
                 "split-bf16 output: cout and y_ld in multiples of 8, y 32-byte aligned");
-  if (residual != nullptr && (d->in_dtype == FSS_F32_BF16X3 || (d->in_dtype == FSS_F16 && d->out_dtype == FSS_F32_BF16X3)))
+  if (residual != nullptr && (d->in_dtype == FSS_F32_BF16X3 || (f16_in && d->out_dtype == FSS_F32_BF16X3)))
     FSS_REQUIRE(d->res_ld % 8 == 0 && ((uintptr_t)residual & 31) == 0,
                 "split-bf16 residual: res_ld a multiple of 8, 32-byte aligned");
   FSS_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->cout > 0, "bad shape");
@@ -152,7 +157,7 @@ extern "C" int fss_conv2d_dual_nhwc(const fss_conv_desc* d, const void* x, const
   ConvArgs a;
   if (int rc = conv_setup(d, x, x2, cin2, w_packed, bias, residual, y, a)) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (d->in_dtype == FSS_F16 || d->out_dtype == FSS_F16)
+  if (d->in_dtype == FSS_F16 || d->in_dtype == FSS_F16_W2 || d->out_dtype == FSS_F16)
     return dispatch_conv_half(a, d->in_dtype, d->out_dtype, d->config, s);
   if (d->in_dtype == FSS_F32) return dispatch_conv<float, float>(a, d->config, s);
   if (d->in_dtype == FSS_F32_BF16X3 && d->out_dtype == FSS_F32_BF16X3) return dispatch_conv<f32s_t, f32s_t>(a, d->config, s);
@@ -240,6 +245,7 @@ extern "C" int fss_conv2d_splitk_nhwc(const fss_conv_desc* d, const void* x, con
                                       float* workspace, size_t workspace_bytes, void* stream) {
   FSS_REQUIRE(splits >= 2 && splits <= 16, "splits must be 2..16");
   FSS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "null or unaligned workspace");
+  FSS_REQUIRE(d == nullptr || d->in_dtype != FSS_F16_W2, "no split-K form of FSS_F16_W2");
   ConvArgs a;
   if (int rc = conv_setup(d, x, nullptr, 0, w_packed, bias, residual, y, a)) return rc;
   const int ld = (d->cout + 3) / 4 * 4;

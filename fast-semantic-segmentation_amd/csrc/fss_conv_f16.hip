@@ -11,6 +11,8 @@ int dispatch_conv_half(ConvArgs& a, int in_dtype, int out_dtype, int config, hip
   if (in_dtype == FSS_F16 && out_dtype == FSS_F32) return dispatch_conv<f16_t, float>(a, config, stream);
   if (in_dtype == FSS_F16 && out_dtype == FSS_F32_BF16X3) return dispatch_conv<f16_t, f32s_t>(a, config, stream);
   if (in_dtype == FSS_F32_BF16X3 && out_dtype == FSS_F16) return dispatch_conv<f32s_t, f16_t>(a, config, stream);
+  if (in_dtype == FSS_F16_W2 && out_dtype == FSS_F16) return dispatch_conv<f16w_t, f16_t>(a, config, stream);
+  if (in_dtype == FSS_F16_W2 && out_dtype == FSS_F32_BF16X3) return dispatch_conv<f16w_t, f32s_t>(a, config, stream);
   set_error("fss_conv2d_nhwc: unsupported combination of FSS_F16 with another dtype");
   return 2;
 }

@@ -64,6 +64,8 @@ template <> struct Mma<f16_t, 16> : Mma<bf16_t, 16> {
                                                  __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
   }
 };
+// half-precision activations against two-f16 weights: the f16 MFMA, once per weight part
+template <> struct Mma<f16w_t, 16> : Mma<f16_t, 16> {};
 template <> struct Mma<float, 32> {
   typedef f32x16 acc_t;
   static constexpr int NREG = 16;
@@ -129,11 +131,16 @@ conv_igemm_kernel(const ConvArgs a) {
   constexpr int BK = CPR * EPC;             // K elements per tile
   constexpr int A_CHUNKS = BM * CPR, B_CHUNKS = BN * CPR;
   constexpr int A_IT = A_CHUNKS / NT, B_IT = B_CHUNKS / NT;
-  constexpr int LOADS = A_IT + B_IT;        // DMA pieces per wave per stage
+  // WIDE: the B operand comes as two tiles per stage, the high parts of the weights and their
+  // remainders (k_pad elements further along the packed row); every MFMA step runs once per part
+  constexpr bool WIDE = std::is_same<T, f16w_t>::value;
+  constexpr int BPL = WIDE ? 2 : 1;
+  static_assert(!(WIDE && HEAD), "no classifier-head form of the two-part weight mode");
+  constexpr int LOADS = A_IT + BPL * B_IT;  // DMA pieces per wave per stage
   constexpr int RSTEP = NT / CPR;           // row step between a thread's chunks
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / FM, NI = WTN / FM;
-  constexpr int STAGE_BYTES = (BM + BN) * BKB;
+  constexpr int STAGE_BYTES = (BM + BPL * BN) * BKB;
   // XOR term of the chunk index of a tile row.  ds_read_b128 serves a wave in four fixed
   // groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32); with
   // these terms the 16 (row, chunk) pairs of every group fall on 16 different 16-byte
@@ -183,7 +190,8 @@ conv_igemm_kernel(const ConvArgs a) {
       reinterpret_cast<const char*>(a.x2 != nullptr ? a.x2 : a.x) + x2_first,
       (unsigned long long)a.M * a.Cin2 * sizeof(T) - x2_first);
   const fss_i32x4 rs_w = dma_resource(
-      reinterpret_cast<const char*>(a.w) + (size_t)tile_n * BN * a.Kpad * sizeof(T), (size_t)BN * a.Kpad * sizeof(T));
+      reinterpret_cast<const char*>(a.w) + (size_t)tile_n * BN * a.Kpad * BPL * sizeof(T),
+      (size_t)BN * a.Kpad * BPL * sizeof(T));
   // ---- per-row gather state
   // ALIGNED: roff = byte offset of this lane's chunk at tap (0,0) in the input window (modulo
   //          2^32: exact once a real tap's offset is added), tapmask bit t = tap t of this row
@@ -242,7 +250,7 @@ conv_igemm_kernel(const ConvArgs a) {
       const int l = wrow % (BN / WAVES_N);
       wrow += (((l >> 5) << 5) + (((l >> 2) & 3) << 3) + (((l >> 4) & 1) << 2) + (l & 3)) - l;
     }
-    woff[i] = (unsigned)(((size_t)wrow * a.Kpad + chunk * EPC) * sizeof(T));
+    woff[i] = (unsigned)(((size_t)wrow * a.Kpad * BPL + chunk * EPC) * sizeof(T));
   }
 
   // tap walk.  ALIGNED: (kc, tap = kr*KW + ks) = channel base / tap of the whole tile
@@ -341,6 +349,12 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < B_IT; ++i)
       blds16(w_ok ? woff[i] + (unsigned)wk : kDmaOutOfRange, rs_w, dstB + i * (NT * 16));
+    if constexpr (WIDE) {
+      const unsigned lo_off = (unsigned)wk + (unsigned)(a.Kpad * (int)sizeof(T));
+#pragma unroll
+      for (int i = 0; i < B_IT; ++i)
+        blds16(w_ok ? woff[i] + lo_off : kDmaOutOfRange, rs_w, dstB + BN * BKB + i * (NT * 16));
+    }
     advance();
   };
 
@@ -377,7 +391,7 @@ conv_igemm_kernel(const ConvArgs a) {
   TO* __restrict__ yg = reinterpret_cast<TO*>(a.y) + (size_t)zsplit * a.M * a.y_ld;
   // the residual has the input's type; with half-precision input, the OUTPUT's (a float residual
   // stream can then take the result of a half-precision stretch of the graph)
-  typedef typename std::conditional<std::is_same<T, f16_t>::value, TO, T>::type TR;
+  typedef typename std::conditional<std::is_same<T, f16_t>::value || WIDE, TO, T>::type TR;
   const TR* __restrict__ rg = reinterpret_cast<const TR*>(a.res);
   const int n_base = tile_n * BN + wn * WTN;
   const bool vec_ok = ((a.y_ld & (VW - 1)) == 0) && ((a.Cout & (VW - 1)) == 0) &&
@@ -438,6 +452,16 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int j = 0; j < NI; ++j)
         fb[j] = *reinterpret_cast<const uint4*>(pb + j * FM * BKB + frag_off[s]);
+      if constexpr (WIDE) {
+        uint4 fl[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          fl[j] = *reinterpret_cast<const uint4*>(pb + BN * BKB + j * FM * BKB + frag_off[s]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) MMA::run(acc[i][j], fa[i], fl[j]);    // the small terms first
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -878,7 +902,7 @@ template <typename T, typename TO, int BM, int BN, int WAVES_M, int WAVES_N, int
           int FM, bool ALIGNED, bool HEAD = false>
 static int launch_conv_impl(ConvArgs& a, hipStream_t stream) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr size_t smem = (size_t)NSTAGE * (BM + BN) * BKB;
+  constexpr size_t smem = (size_t)NSTAGE * (BM + (std::is_same<T, f16w_t>::value ? 2 : 1) * BN) * BKB;
   a.tiles_m = ceil_div(a.M, BM);
   a.tiles_n = ceil_div(a.Cout, BN);
   const long long blocks = (long long)a.tiles_m * a.tiles_n * a.splits;
@@ -990,10 +1014,12 @@ static int default_config(const ConvArgs& a) {
 template <typename T, typename TO>
 static int dispatch_conv(ConvArgs& a, int config, hipStream_t stream) {
   // half-precision tensors (in or out) come with the 16x16 MFMA configurations only
-  constexpr bool kHalf = std::is_same<T, f16_t>::value || std::is_same<TO, f16_t>::value;
+  constexpr bool kWide = std::is_same<T, f16w_t>::value;
+  constexpr bool kHalf = std::is_same<T, f16_t>::value || std::is_same<TO, f16_t>::value || kWide;
   if (config == 0) {
     if (!kHalf) config = default_config(a);
     else if (std::is_same<T, f32s_t>::value) config = a.Cout <= 64 ? 18 : 16;   // even k steps per tile
+    else if (kWide) config = a.Cout <= 32 ? 24 : a.Cout <= 64 ? 19 : 14;                // rings that fit
     else config = a.Cout <= 32 ? 24 : a.Cout <= 64 ? 19 : 16;
   }
   if (config == kConv8Config) {
@@ -1006,14 +1032,17 @@ static int dispatch_conv(ConvArgs& a, int config, hipStream_t stream) {
   switch (config) {
 #define FSS_CASE(ID, BM, BN, WM, WN, BKB, NS, FM)                                        \
   case ID:                                                                               \
-    if constexpr (!kHalf || FM == 16) return launch_conv<T, TO, BM, BN, WM, WN, BKB, NS, FM>(a, stream); \
+    if constexpr ((!kHalf || FM == 16) && (!kWide || NS * (BM + 2 * BN) * BKB < 160 * 1024)) \
+      return launch_conv<T, TO, BM, BN, WM, WN, BKB, NS, FM>(a, stream);                 \
     else break;
     FSS_CONV_CONFIGS(FSS_CASE)
 #undef FSS_CASE
     default: break;
   }
-  set_error(kHalf ? "fss_conv2d_nhwc: FSS_F16 tensors need a 16x16-MFMA configuration"
-                  : "fss_conv2d_nhwc: unknown config");
+  set_error(kWide ? "fss_conv2d_nhwc: FSS_F16_W2 needs a 16x16-MFMA configuration whose ring fits the LDS "
+                    "with two weight tiles per stage"
+            : kHalf ? "fss_conv2d_nhwc: FSS_F16 tensors need a 16x16-MFMA configuration"
+                    : "fss_conv2d_nhwc: unknown config");
   return 2;
 }
 

@@ -1000,7 +1000,8 @@ extern "C" {
 int fss_maxpool_nhwc(const void* x, void* y, int n, int h, int wd, int c, int k, int stride,
                      int pad_top, int pad_left, int ho, int wo, int dtype, void* stream) {
   FSS_REQUIRE(x && y, "null argument");
-  FSS_DTYPE_OK(dtype);
+  // (half precision too: the largest of a set of half-precision numbers is one of them)
+  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F32_BF16X3 || dtype == FSS_F16, "bad dtype");
   FSS_CHUNK_OK(c, dtype);
   FSS_ALIGNED(x); FSS_ALIGNED(y);
   FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0 && k > 0 && stride > 0, "bad shape");
@@ -1016,6 +1017,9 @@ int fss_maxpool_nhwc(const void* x, void* y, int n, int h, int wd, int c, int k,
   else if (dtype == FSS_F32_BF16X3)
     hipLaunchKernelGGL(maxpool_kernel<f32s_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const f32s_t*)x, (f32s_t*)y, n, h, wd, c, k, stride, pad_top, pad_left, ho, wo);
+  else if (dtype == FSS_F16)
+    hipLaunchKernelGGL(maxpool_kernel<f16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const f16_t*)x, (f16_t*)y, n, h, wd, c, k, stride, pad_top, pad_left, ho, wo);
   else
     hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const bf16_t*)x, (bf16_t*)y, n, h, wd, c, k, stride, pad_top, pad_left, ho, wo);

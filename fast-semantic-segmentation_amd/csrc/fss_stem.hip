@@ -78,8 +78,9 @@ template <> struct StemPix<float> {
 template <typename T, int NJ, int KS, typename TO = T, bool SPLIT = false>
 __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
   constexpr int ES = (int)sizeof(T);
-  static_assert(!SPLIT || (std::is_same<T, f16_t>::value && sizeof(TO) == 4),
-                "float-quality mode: f16 operands, split-bfloat16 output");
+  static_assert(!SPLIT || (std::is_same<T, f16_t>::value &&
+                           (std::is_same<TO, f32s_t>::value || std::is_same<TO, f16_t>::value)),
+                "float-quality mode: f16 operands, split-bfloat16 or half-precision output");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* tapoff = reinterpret_cast<int*>(smem);            // 64 patch offsets (in pixels)
   const int WROW = a.K4pad * ES + 16;                    // +16: rows land on distinct banks
@@ -124,8 +125,10 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
       const int co = chan_of(nj, g, q);
       bias[nj][q] = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
     }
-  const float act_lo = a.act == FSS_ACT_NONE ? -INFINITY : 0.f;
-  const float act_hi = a.act == FSS_ACT_RELU6 ? 6.f : INFINITY;
+  // (half-precision outputs saturate instead of overflowing to infinity)
+  constexpr float kOutMax = std::is_same<TO, f16_t>::value ? 65504.f : INFINITY;
+  const float act_lo = a.act == FSS_ACT_NONE ? -kOutMax : 0.f;
+  const float act_hi = a.act == FSS_ACT_RELU6 ? 6.f : kOutMax;
   // whole-lane vector stores need every lane's piece 16-byte aligned
   // (split-bf16 output: a lane's 4*NJ consecutive channels must be whole groups of 8)
   const bool vec_ok = (a.y_ld * (int)sizeof(TO)) % (SPLIT_OUT ? 32 : 16) == 0 && (!SPLIT_OUT || NJ % 2 == 0) &&
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(256) stem_conv_kernel(const StemArgs a) {
           unsigned o[2 * NJ];
 #pragma unroll
           for (int e = 0; e < 2 * NJ; ++e)
-            o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            o[e] = Half16<TO>::pack2(v[2 * e], v[2 * e + 1]);
           if constexpr (NJ % 2 == 0) {
 #pragma unroll
             for (int e = 0; e < NJ / 2; ++e)
@@ -463,7 +466,8 @@ using namespace fss;
 extern "C" int fss_stem_pack_dims(int kh, int kw, int cout, int dtype, int* k_pad, int* cout_pad) {
   FSS_REQUIRE(k_pad && cout_pad, "null argument");
   // (FSS_F16: the first layer of fss_stem2_conv_u8; same dimensions as bfloat16)
-  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F32_BF16X3 || dtype == FSS_F16, "bad dtype");
+  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F32_BF16X3 || dtype == FSS_F16 ||
+                  dtype == FSS_F16_W2, "bad dtype");
   FSS_REQUIRE(kh > 0 && kw > 0 && kh * kw <= 64 && cout > 0 && cout <= 64, "bad shape");
   const int k4 = kh * kw * 4;
   *k_pad = dtype != FSS_F32 ? (k4 + 31) / 32 * 32 : k4;
@@ -477,7 +481,7 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
                                 int dilation, int pad_top, int pad_left, int ho, int wo, int act,
                                 int dtype, int y_ld, void* stream) {
   FSS_REQUIRE(x && w_packed && y && mean3 && scale3, "null argument");
-  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F32_BF16X3, "bad dtype");
+  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F32_BF16X3 || dtype == FSS_F16_W2, "bad dtype");
   FSS_REQUIRE(n > 0 && hr > 0 && wr > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "bad shape");
   FSS_REQUIRE(sub >= 1 && sub <= 8, "sub must be in [1, 8]");
   FSS_REQUIRE(kh > 0 && kw > 0 && kh * kw <= 64, "filter must have at most 64 taps");
@@ -518,7 +522,8 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
   a.total_tiles = (int)total;
   for (int i = 0; i < 3; ++i) { a.mean[i] = mean3[i]; a.scale[i] = scale3[i]; }
   a.unit_scale = scale3[0] == 1.f && scale3[1] == 1.f && scale3[2] == 1.f;
-  const int es = dtype == FSS_F32 ? 4 : 2, wplanes = dtype == FSS_F32_BF16X3 ? 2 : 1;
+  const bool raw = dtype == FSS_F32_BF16X3 || dtype == FSS_F16_W2;     // the float-quality form
+  const int es = dtype == FSS_F32 ? 4 : 2, wplanes = raw ? 2 : 1;
   const size_t smem = 256 + wplanes * (size_t)cout_pad * (k_pad * es + 16) + (size_t)a.PH * a.PW * 4 * es;
   FSS_REQUIRE(smem <= 160 * 1024, "filter too large for LDS");
   hipStream_t s = (hipStream_t)stream;
@@ -540,6 +545,15 @@ extern "C" int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const fl
       case 2: return launch_stem<f16_t, 2, 0, f32s_t, true>(a, smem, s);
       case 3: return launch_stem<f16_t, 3, 0, f32s_t, true>(a, smem, s);
       default: return launch_stem<f16_t, 4, 0, f32s_t, true>(a, smem, s);
+    }
+  }
+  if (dtype == FSS_F16_W2) {
+    if (nj == 4 && k_pad == 224) return launch_stem<f16_t, 4, 7, f16_t, true>(a, smem, s);
+    switch (nj) {
+      case 1: return launch_stem<f16_t, 1, 0, f16_t, true>(a, smem, s);
+      case 2: return launch_stem<f16_t, 2, 0, f16_t, true>(a, smem, s);
+      case 3: return launch_stem<f16_t, 3, 0, f16_t, true>(a, smem, s);
+      default: return launch_stem<f16_t, 4, 0, f16_t, true>(a, smem, s);
     }
   }
   // the two filters of the reference's networks: unrolled tap walk

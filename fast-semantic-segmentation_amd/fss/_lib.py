@@ -11,8 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('FSS_LIB') or os.path.join(os.path.dirname(_HERE), 'libfss_gfx950.so')
 
 F32, BF16 = 0, 1
-F32_BF16X3 = 2      # fss_conv_desc.in_dtype only: float storage, split-bf16 products
+F32_BF16X3 = 2      # split-bfloat16 tensors (two bf16 numbers per value), three MFMAs per product
 F16 = 3             # IEEE half precision tensors (convolution entry points only)
+F16_W2 = 4          # fss_conv_desc.in_dtype only: F16 activations, weights as two f16 numbers each
 PYRAMID_STATIC_MAX_BYTES = 32 << 20     # FSS_PYRAMID_STATIC_MAX_BYTES
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 ACT_CODES = {None: ACT_NONE, 'relu': ACT_RELU, 'relu6': ACT_RELU6}

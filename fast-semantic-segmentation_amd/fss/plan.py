@@ -60,8 +60,11 @@ DEFAULT_HALF_SCOPES = (r'/bottleneck_v1/conv2$', r'^Conv(_[123])?$')
 # error per element that averages out over the K axis; rounding a weight is the same error for
 # every pixel.  On the float32 oracle, 11-bit activations in every conv3 raise the rms logit error
 # of the mode from 1.82e-4 to 1.93e-4 of the logit rms (tools/precision_emulation.py style run),
-# where 11-bit weights in the same layers cost several times that.
-DEFAULT_HALF_ACT_SCOPES = (r'/bottleneck_v1/conv3$',)
+# where 11-bit weights in the same layers cost several times that.  The two convolutions that read
+# the max-pooled output of the first convolution (conv1 and the projection shortcut of the first
+# unit) take half-precision activations as well, so that the largest tensor of the backbone and
+# its pooled form are written and read at two bytes per element (rms logit error 2.25e-4).
+DEFAULT_HALF_ACT_SCOPES = (r'/bottleneck_v1/conv3$', r'/block1/unit_1/bottleneck_v1/(conv1|shortcut)$')
 
 
 def f32_to_bf16_bits(a):
@@ -75,6 +78,14 @@ def f32_to_f16_bits(a):
     """float32 ndarray -> uint16 ndarray of IEEE half bits (round to nearest even, saturating)."""
     a = np.clip(np.ascontiguousarray(a, dtype=np.float32), -65504.0, 65504.0)
     return a.astype(np.float16).view(np.uint16)
+
+
+def f32_split_f16_rows(Wp):
+    """Packed float32 weights [cout_pad][k_pad] -> uint16 [cout_pad][2 * k_pad]: every row's
+    IEEE-half high parts followed by its remainders (the FSS_F16_W2 convolutions)."""
+    hi = f32_to_f16_bits(Wp)
+    lo = f32_to_f16_bits(np.asarray(Wp, np.float32) - hi.view(np.float16).astype(np.float32))
+    return np.ascontiguousarray(np.concatenate([hi, lo], axis=1))
 
 
 def stem_pack_f16x2(W, mean, scale, cout_pad, k_pad):
@@ -354,6 +365,8 @@ class CompiledGraph(object):
             dev = torch.from_numpy(f32_to_bf16_bits(Wp).view(np.int16)).to(self.device)
         elif dt == 'f16':
             dev = torch.from_numpy(f32_to_f16_bits(Wp).view(np.int16)).to(self.device)
+        elif dt == 'f16w':
+            dev = torch.from_numpy(f32_split_f16_rows(Wp).view(np.int16)).to(self.device)
         elif dt == 'f32s':
             dev = torch.from_numpy(f32_split_bf16_rows(Wp).view(np.int16)).to(self.device)
         else:
@@ -382,13 +395,20 @@ class CompiledGraph(object):
             return False
         if not self.fuse_dual:
             return True
-        # not when it shares a launch with a projection shortcut (whose input is not half precision)
+        # a convolution that shares a launch with another one (projection shortcut + last 1x1):
+        # only when both are named, so that both inputs are half precision
+        mate = self._dual_partner(ln)
         add = self._only_consumer(ln, 'add')
-        if add is not None:
+        if mate is None and add is not None:
             for other in add.inputs:
                 if other is not ln and other.kind == 'conv2d' and self._dual_partner(other) is ln:
-                    return False
-        return ln not in self.dual and self._dual_partner(ln) is None
+                    mate = other
+        if mate is None:
+            return ln not in self.dual
+        ms = mate.attrs['weights'].rsplit('/', 1)[0]
+        return (any(r.search(ms) for r in self.half_act_re) and not self._is_half_conv(mate)
+                and (mate.attrs['kh'], mate.attrs['kw'], mate.attrs['rate']) == (1, 1, 1)
+                and mate.inputs[0].shape[3] % 64 == 0)
 
     def _store_dt(self, result, in_dt):
         """Storage type of the tensor `result` a convolution reading `in_dt` tensors produces.
@@ -401,6 +421,8 @@ class CompiledGraph(object):
         for c in result.consumers:
             if c.kind == 'conv2d' and c.inputs[0] is result and (self._is_half_conv(c) or self._takes_half_acts(c)):
                 continue
+            if c.kind == 'max_pool' and c.attrs['k'] > 1 and not c.is_output and self._store_dt(c, in_dt) == 'f16':
+                continue        # the largest of half-precision numbers is one of them
             if c.kind == 'add' and len(c.inputs) == 2:
                 # a residual: the half-precision convolution that absorbs the add reads it in the
                 # type it stores its own result in
@@ -564,6 +586,9 @@ class CompiledGraph(object):
         k_pad, cout_pad = ctypes.c_int(0), ctypes.c_int(0)
         nxt, dt2 = self._stem2_partner(ln)
         code = _CODE[dt2] if nxt is not None else self._in_code(self.dt)
+        out_dt = self.dt
+        if nxt is None and self.split and self._store_dt(ln, self.dt) == 'f16':
+            out_dt, code = 'f16', _lib.F16_W2       # every reader takes half-precision activations
         _lib.call('fss_stem_pack_dims', kh, kw, cout, code, ctypes.byref(k_pad),
                   ctypes.byref(cout_pad))
         Wp = np.zeros((cout_pad.value, k_pad.value), np.float32)
@@ -584,15 +609,15 @@ class CompiledGraph(object):
         sc = (ctypes.c_float * 3)(*pre.attrs['scale'])
         if nxt is not None:
             return self._l_stem2_conv(ln, nxt, x, sub, h, w, wdev, bdev, mean, sc, dt2)
-        out = Val(self._alloc(ln.shape, self.dt), ln.shape, self.dt)
+        out = Val(self._alloc(ln.shape, out_dt), ln.shape, out_dt)
         self.vals[ln] = out
         self._emit('stem', a['weights'].rsplit('/', 1)[0], 'fss_stem_conv_u8',
                    (x.ptr, wdev.data_ptr(), bdev.data_ptr(), out.ptr, n, hr, wr, sub, h, w, mean, sc,
                     cout, kh, kw, a['stride'], a['rate'], a['pad_top'], a['pad_left'], ho, wo,
                     _lib.ACT_CODES[a['activation']], code, out.ld, self.sh),
                    flops=2 * n * ho * wo * cout * kh * kw * 3,
-                   nbytes=n * (hr // sub) * (wr // sub) * 3 + n * ho * wo * cout * _ESZ[self.dt],
-                   keep=(mean, sc), mpp=2 if code == _lib.F32_BF16X3 else 1)
+                   nbytes=n * (hr // sub) * (wr // sub) * 3 + n * ho * wo * cout * _ESZ[out_dt],
+                   keep=(mean, sc), mpp=2 if code in (_lib.F32_BF16X3, _lib.F16_W2) else 1)
 
     def _stem2_partner(self, ln):
         """(the convolution that consumes stem conv `ln`, the 16-bit type) when both can run as
@@ -920,7 +945,9 @@ class CompiledGraph(object):
         Wp = np.zeros((cout_pad, k_pad), np.float32)
         Wp[:cout, :kh * kw * cin] = WB.transpose(3, 0, 1, 2).reshape(cout, -1)
         Wp[:cout, kh * kw * cin:k] = WA.reshape(cin2, cout).T
-        wdev = self._pack(Wp, x.dt)
+        # half-precision inputs of convolutions that keep float-quality weights (FSS_F16_W2)
+        wide = x.dt == 'f16' and self._takes_half_acts(A) and self._takes_half_acts(B)
+        wdev = self._pack(Wp, 'f16w' if wide else x.dt)
         bdev = self._dev_f32(bA + bB)
         self.param_bytes += cout * k * _ESZ[x.dt]
         name = b['weights'].rsplit('/', 1)[0] + '+' + A.attrs['weights'].rsplit('/', 2)[-2]
@@ -941,14 +968,15 @@ class CompiledGraph(object):
             self.vals[node] = out
         d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
                           dilation=b['rate'], pad_top=b['pad_top'], pad_left=b['pad_left'],
-                          ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=self._in_code(x.dt),
+                          ho=ho, wo=wo, act=_lib.ACT_CODES[act],
+                          in_dtype=_lib.F16_W2 if wide else self._in_code(x.dt),
                           out_dtype=_CODE[out_dt], y_ld=out.ld, res_ld=0, k_pad=k_pad, cout_pad=cout_pad)
-        nbytes = ((n * h * w * cin + n * ho * wo * cin2 + cout * k) * _ESZ[x.dt]
+        nbytes = ((n * h * w * cin + n * ho * wo * cin2 + cout * k * (2 if wide else 1)) * _ESZ[x.dt]
                   + n * ho * wo * cout * _ESZ[out_dt])
         self._emit('conv', name, 'fss_conv2d_dual_nhwc',
                    (ctypes.byref(d), x.ptr, x2.ptr, cin2, wdev.data_ptr(), bdev.data_ptr(), None,
                     out.ptr, self.sh),
-                   flops=2 * n * ho * wo * cout * k, nbytes=nbytes, keep=d)
+                   flops=2 * n * ho * wo * cout * k, nbytes=nbytes, keep=d, mpp=2 if wide else 1)
 
     def _pyramid_source(self, ln):
         """(base node, level values) when conv `ln` is the 1x1 convolution behind the deferred sum
@@ -1108,26 +1136,20 @@ class CompiledGraph(object):
                        nbytes=(n * h * w * cin + n * ho * wo * cout + cout * 9 * cin) * 2)
             return
         if in_dt == 'f16' and pc == cin and self._takes_half_acts(ln):
-            # half-precision activations, float-quality weights: W = hi + lo with hi = f16(W),
-            # lo = f16(W - hi), as the two filters of a two-input launch that reads x twice
-            hi = f32_to_f16_bits(Wp[:, :cin]).view(np.float16).astype(np.float32)
-            k_pad2 = (2 * cin + 63) // 64 * 64
-            W2 = np.zeros((cout_pad, k_pad2), np.float32)
-            W2[:, :cin] = hi
-            W2[:, cin:2 * cin] = Wp[:, :cin] - hi
-            wdev = self._pack(W2, 'f16')
+            # half-precision activations, float-quality weights (FSS_F16_W2): per output channel
+            # the k_pad high parts f16(W), then the k_pad remainders f16(W - high)
             out = Val(self._alloc(ln.shape, out_dt), ln.shape, out_dt)
             self.vals[result] = out
             if result is not ln:
                 self.vals[ln] = out
             d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=1, kw=1, stride=1, dilation=1, pad_top=0,
-                              pad_left=0, ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_CODE['f16'],
+                              pad_left=0, ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_lib.F16_W2,
                               out_dtype=_CODE[out_dt], y_ld=out.ld, res_ld=res.ld if res else 0,
-                              k_pad=k_pad2, cout_pad=cout_pad)
+                              k_pad=k_pad, cout_pad=cout_pad)
             nbytes = ((n * h * w * cin + 2 * cout * cin) * 2 + n * ho * wo * cout * _ESZ[out_dt]
                       + (n * ho * wo * cout * _ESZ[res.dt] if res else 0))
-            self._emit('conv', a['weights'].rsplit('/', 1)[0], 'fss_conv2d_dual_nhwc',
-                       (ctypes.byref(d), x.ptr, x.ptr, cin, wdev.data_ptr(), bdev.data_ptr(),
+            self._emit('conv', a['weights'].rsplit('/', 1)[0], 'fss_conv2d_nhwc',
+                       (ctypes.byref(d), x.ptr, self._pack(Wp, 'f16w').data_ptr(), bdev.data_ptr(),
                         res.ptr if res else None, out.ptr, self.sh),
                        flops=2 * n * ho * wo * cout * cin, nbytes=nbytes, keep=d, mpp=2)
             return
@@ -1466,7 +1488,7 @@ class CompiledGraph(object):
         info = (ctypes.c_int * 7)()
         # candidates of the plan's MFMA shape; the split-bf16 launches take only those with an
         # even number of k steps per tile
-        all_cands, split_cands, tile_n = [], [], {}
+        all_cands, split_cands, wide_cands, tile_n = [], [], [], {}
         small_all, small_split = [], []
         for cfg in range(1, ncfg + 1):
             _lib.call('fss_conv_config_info', cfg, info)
@@ -1475,6 +1497,9 @@ class CompiledGraph(object):
             even = (info[4] // (16 * (64 // info[6]))) % 2 == 0
             all_cands.append(cfg)
             tile_n[cfg] = info[1]
+            # two weight tiles per stage (FSS_F16_W2): the ring must still fit the LDS
+            if info[5] * (info[0] + 2 * info[1]) * info[4] < 160 * 1024 and cfg != 35:
+                wide_cands.append(cfg)
             if even:
                 split_cands.append(cfg)
             # small-tile configurations: the ones a split-K launch is tried with
@@ -1492,6 +1517,8 @@ class CompiledGraph(object):
             key = ','.join(str(getattr(d, f[0])) for f in d._fields_ if f[0] != 'config')
             x3 = d.in_dtype == _lib.F32_BF16X3
             candidates, small = (split_cands, small_split) if x3 else (all_cands, small_all)
+            if d.in_dtype == _lib.F16_W2:
+                candidates = wide_cands
             cands = candidates
             # split-K candidates: an output too small to fill the chip (at most four 64x64 tiles
             # per CU) under a long K axis, i.e. the late backbone blocks at one or two frames

@@ -53,6 +53,15 @@ extern "C" {
  * output, or read FSS_F16 and store float, which is how half-precision stretches of a graph
  * join the float ones. */
 #define FSS_F16 3
+/* fss_conv_desc.in_dtype only: FSS_F16 activations against weights of float quality.  The packed
+ * weights hold, per output channel, the k_pad IEEE-half high parts f16(W) followed by the k_pad
+ * remainders f16(W - high) ([cout_pad][2 * k_pad], dims from fss_conv_pack_dims); every product
+ * is two f16 MFMAs.  Rounding an activation to half precision is an independent error per
+ * element that averages out over the K axis, where a rounded weight repeats its error at every
+ * pixel: this mode takes the first and avoids the second.  out_dtype FSS_F16 or
+ * FSS_F32_BF16X3; the residual has the output's type; configurations whose ring does not fit
+ * the LDS with the doubled weight tile are rejected. */
+#define FSS_F16_W2 4
 
 #define FSS_ACT_NONE 0
 #define FSS_ACT_RELU 1
@@ -255,7 +264,7 @@ int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y,
                       int dilation, int pad_top, int pad_left, int ho, int wo,
                       int act, int dtype, void* stream);
 
-/* Max pooling; padded taps are ignored.
+/* Max pooling; padded taps are ignored.  dtype may also be FSS_F16.
  * Replaces slim.max_pool2d(net, [3,3], stride=2) under SAME
  * (third_party/dilated_resnet_v1.py:175). */
 int fss_maxpool_nhwc(const void* x, void* y, int n, int h, int wd, int c, int k,
@@ -364,6 +373,7 @@ int fss_preprocess_u8(const uint8_t* x, void* y, int n, int h, int wd, int ho,
  * mean[c] * scale[c] - and packs them as two IEEE-half matrices [cout_pad][k_pad], the high parts
  * f16(W') followed by the remainders f16(W' - high) (dims from fss_stem_pack_dims with that
  * dtype); mean3 / scale3 are not used.  No activation is rounded and a product costs two MFMAs.
+ * dtype FSS_F16_W2: the same arithmetic and weights with FSS_F16 output (saturating).
  * Limits: cout <= 64, kh*kw <= 64, stride, dilation <= 4. */
 int fss_stem_pack_dims(int kh, int kw, int cout, int dtype, int* k_pad, int* cout_pad);
 int fss_stem_conv_u8(const uint8_t* x, const void* w_packed, const float* bias, void* y,

@@ -6,12 +6,15 @@ import numpy as np
 import torch
 
 from fss import _lib
-from fss.plan import f32_to_bf16_bits, f32_to_f16_bits, f32_split_bf16_rows, split_bf16_decode, split_bf16_encode
+from fss.plan import (f32_to_bf16_bits, f32_to_f16_bits, f32_split_bf16_rows, f32_split_f16_rows,
+                      split_bf16_decode, split_bf16_encode)
 
 # 'f32x3': split-bfloat16 tensors (FSS_F32_BF16X3: 4-byte slots, per 8 channels 8 bf16 high parts
 # then 8 bf16 remainders); convolutions form their products from them as three bf16 MFMAs
 DT = {'f32': (_lib.F32, torch.float32, 4), 'bf16': (_lib.BF16, torch.bfloat16, 8),
-      'f32x3': (_lib.F32_BF16X3, torch.float32, 8), 'f16': (_lib.F16, torch.float16, 8)}
+      'f32x3': (_lib.F32_BF16X3, torch.float32, 8), 'f16': (_lib.F16, torch.float16, 8),
+      # convolution input only: f16 activations against weights kept as two f16 numbers each
+      'f16w': (_lib.F16_W2, torch.float16, 8)}
 
 
 def x3_round(a):
@@ -72,6 +75,8 @@ def pack_conv_weights(w, dt, cin_phys=None):
         dev = torch.from_numpy(half_bits(wp, dt).view(np.int16)).cuda()
     elif dt == 'f32x3':
         dev = torch.from_numpy(f32_split_bf16_rows(wp).view(np.int16)).cuda()
+    elif dt == 'f16w':
+        dev = torch.from_numpy(f32_split_f16_rows(wp).view(np.int16)).cuda()
     else:
         dev = torch.from_numpy(wp).cuda()
     return dev, k_pad, cout_pad
@@ -89,7 +94,7 @@ def conv2d(x, w, bias=None, residual=None, stride=1, rate=1, pads=(0, 0), out_hw
     wdev, k_pad, cout_pad = pack_conv_weights(w, dt)
     bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda() if bias is not None else None
     # the residual has the input's type; for half-precision input, the output's
-    rd = to_dev(residual, out_dt if dt == 'f16' else dt) if residual is not None else None
+    rd = to_dev(residual, out_dt if dt in ('f16', 'f16w') else dt) if residual is not None else None
     ld = y_ld or cout
     y = torch.full((n, ho, wo, ld), -77.0, dtype=DT[out_dt][1], device='cuda')
     d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride,
@@ -130,6 +135,8 @@ def conv2d_dual(x, w, x2, w2, bias, stride=1, rate=1, pads=(0, 0), out_hw=None, 
         wdev = torch.from_numpy(half_bits(wp, dt).view(np.int16)).cuda()
     elif dt == 'f32x3':
         wdev = torch.from_numpy(f32_split_bf16_rows(wp).view(np.int16)).cuda()
+    elif dt == 'f16w':
+        wdev = torch.from_numpy(f32_split_f16_rows(wp).view(np.int16)).cuda()
     else:
         wdev = torch.from_numpy(wp).cuda()
     xd, x2d = to_dev(x, dt), to_dev(x2, dt)

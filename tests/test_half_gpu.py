@@ -178,3 +178,64 @@ def test_half_outputs_round_to_nearest_even():
     w = np.eye(64, dtype=np.float32).reshape(1, 1, 64, 64)
     got = gu.conv2d(x, w, None, None, 1, 1, (0, 0), (16, 16), None, 'f32x3', out_dt='f16')
     assert np.array_equal(got, x.astype(np.float16).astype(np.float32))
+
+
+WIDE_TOL = {'f32x3': 2e-5, 'f16': 1.0 / 1024}
+
+
+@pytest.mark.parametrize('case', [c for c in CONV_CASES if c[3] % 8 == 0])
+@pytest.mark.parametrize('out_dt', ['f32x3', 'f16'])
+def test_conv2d_half_activations_wide_weights(case, out_dt):
+    """FSS_F16_W2: half-precision activations against float weights kept as two f16 numbers.
+    The weights are NOT rounded here, so with split-bfloat16 output the kernel must match the
+    float64 oracle to the 16 bits that output holds - an order of magnitude tighter than the float
+    kernels' 2e-4, and out of reach with weights rounded to half precision."""
+    gu = _gu()
+    n, h, wd, cin, cout, k, stride, rate, mode = case
+    rng = np.random.default_rng(zlib.crc32(repr(case).encode()))
+    x = gu.f16_round(rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32))
+    w = rng.normal(0, 1 / np.sqrt(k * k * cin), (k, k, cin, cout)).astype(np.float32)
+    bias = rng.normal(0, 0.5, cout).astype(np.float32)
+    pads, out_hw = _conv_pads(h, wd, k, stride, rate, mode)
+    ref = _conv_ref(x, w, stride, rate, mode) + bias
+    if out_dt == 'f32x3' and cout % 8:
+        pytest.skip('split-bfloat16 outputs come in groups of 8 channels')
+    got = gu.conv2d(x, w, bias, None, stride, rate, pads, out_hw, None, 'f16w', out_dt=out_dt)
+    _close(got, ref, WIDE_TOL[out_dt], 'conv f16 x two-f16 weights -> %s %s' % (out_dt, case,))
+
+
+def test_conv2d_wide_weights_epilogue_and_configurations():
+    """Residual (split-bfloat16, the output's type) + relu, output in a wider pixel stride; every
+    configuration whose ring fits the LDS with two weight tiles per stage gives the same bits,
+    the others are refused; and the two-input form (projection shortcut + last 1x1)."""
+    gu, L = _gu(), _lib()
+    rng = np.random.default_rng(9)
+    n, h, wd, cin, cout = 2, 21, 19, 128, 264
+    x = gu.f16_round(rng.normal(0, 1, (n, h, wd, cin)).astype(np.float32))
+    w = rng.normal(0, 0.1, (1, 1, cin, cout)).astype(np.float32)
+    bias = rng.normal(0, 1, cout).astype(np.float32)
+    res = gu.x3_round(rng.normal(0, 2, (n, h, wd, cout)).astype(np.float32))
+    ref = O.relu(O.conv2d(x, w, 1, 1, 'SAME', np.float64) + bias + res)
+    first, ran, refused = None, 0, 0
+    info = (ctypes.c_int * 7)()
+    for cfg in range(1, L.lib.fss_conv_config_count() + 1):
+        L.call('fss_conv_config_info', cfg, info)
+        fits = info[6] == 16 and info[5] * (info[0] + 2 * info[1]) * info[4] < 160 * 1024 and cfg != 35
+        if not fits:
+            with pytest.raises(L.FssError, match='16x16'):
+                gu.conv2d(x, w, bias, res, 1, 1, (0, 0), (h, wd), 'relu', 'f16w', out_dt='f32x3', config=cfg)
+            refused += 1
+            continue
+        got = gu.conv2d(x, w, bias, res, 1, 1, (0, 0), (h, wd), 'relu', 'f16w', out_dt='f32x3', y_ld=cout + 16,
+                        config=cfg)
+        _close(got, ref, 2e-5, 'two-f16-weight conv, config %d' % cfg)
+        first = got if first is None else first
+        assert np.array_equal(got, first), 'config %d differs' % cfg
+        ran += 1
+    assert ran >= 10 and refused >= 10
+    x2 = gu.f16_round(rng.normal(0, 1, (n, h, wd, 64)).astype(np.float32))
+    w2 = rng.normal(0, 0.1, (1, 1, 64, cout)).astype(np.float32)
+    ref2 = O.relu(O.conv2d(x, w, 1, 1, 'SAME', np.float64) + O.conv2d(x2, w2, 1, 1, 'SAME', np.float64) + bias)
+    for cfg in (0, 14, 27):
+        out = gu.conv2d_dual(x, w, x2, w2, bias, 1, 1, (0, 0), (h, wd), 'relu', 'f16w', config=cfg, out_dt='f32x3')
+        _close(out, ref2, 2e-5, 'two-input two-f16-weight conv, config %d' % cfg)
