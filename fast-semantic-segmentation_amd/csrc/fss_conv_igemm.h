@@ -992,13 +992,11 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   X(31, 128, 128, 2, 4, 64, 3, 16)  \
   X(32, 128, 64, 4, 2, 128, 2, 16)  \
   X(33, 128, 256, 2, 4, 64, 2, 16)  \
-  X(34, 128, 256, 2, 4, 64, 3, 16)  \
-  X(36, 64, 256, 1, 4, 128, 2, 16)  \
-  X(37, 128, 256, 2, 4, 128, 2, 16)
+  X(34, 128, 256, 2, 4, 64, 3, 16)
 // configuration 35: the 8-wave, 8-phase 256x256 kernel of fss_conv8.hip (bf16 in and out, cin in
 // whole K tiles); for every other layer it stands for configuration 28, whose results are the same
 static constexpr int kConv8Config = 35;
-static constexpr int kNumConvConfigs = 37;
+static constexpr int kNumConvConfigs = 35;
 
 // automatic choice when the caller does not name a configuration
 static int default_config(const ConvArgs& a) {

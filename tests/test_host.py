@@ -266,3 +266,15 @@ def test_filter_pruner_gives_the_half_width_model(tmp_path):
         assert pruned[nxt].shape[2] == len(keep)
     assert compress.main(['--input_checkpoint', str(tmp_path / 'nothing'), '--config_path', 'x',
                           '--prune_config', 'y']) == -1
+
+
+def test_shipped_conv_table_was_measured_with_this_library():
+    """fss/conv_tuned.json carries a stamp of the library version and the tile-configuration
+    table it was measured with; the plan compiler ignores a table whose stamp differs, and
+    would then time every candidate at every plan build."""
+    import json
+    from fss import plan
+    with open(os.path.join(PKG, 'fss', 'conv_tuned.json')) as f:
+        table = json.load(f)
+    assert table['stamp'] == plan.CompiledGraph._tune_stamp(), 'retune: python tools/tune_convs.py --fresh'
+    assert len(table['entries']) > 1000
