@@ -172,10 +172,10 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
                                          const void* w_head, const float* bias_head, int cout_head,
                                          float* y_head, int y_head_ld, void* stream) {
   FSS_REQUIRE(d && w_head && y_head, "null argument");
-  FSS_REQUIRE(d->in_dtype == FSS_BF16 || d->in_dtype == FSS_F32_BF16X3,
-              "the classifier-head form takes bf16 activations, or float ones in the FSS_F32_BF16X3 mode");
+  FSS_REQUIRE(d->in_dtype == FSS_BF16 || d->in_dtype == FSS_F32_BF16X3 || d->in_dtype == FSS_F16_W2,
+              "the classifier-head form takes FSS_BF16, FSS_F32_BF16X3 or FSS_F16_W2 input");
   const unsigned long long esz = d->in_dtype == FSS_BF16 ? 2ull : 4ull;
-  if (d->in_dtype == FSS_F32_BF16X3 && residual != nullptr)
+  if (d->in_dtype != FSS_BF16 && residual != nullptr)
     FSS_REQUIRE(((uintptr_t)residual & 31) == 0, "split-bf16 residual must be 32-byte aligned");
   FSS_REQUIRE(cout_head > 0 && cout_head <= kHeadMax, "cout_head out of range");
   FSS_REQUIRE(y_head_ld >= cout_head, "y_head_ld < cout_head");
@@ -185,6 +185,7 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
   ConvArgs a;
   fss_conv_desc dd = *d;
   dd.y_ld = d->cout;        // no activation tensor is written; keep the shared checks satisfied
+  if (d->in_dtype == FSS_F16_W2) dd.out_dtype = FSS_F32_BF16X3;   // (residuals are split-bfloat16)
   FSS_REQUIRE(residual == nullptr || (((uintptr_t)residual & 15) == 0 && d->res_ld % 8 == 0),
               "unaligned residual");
   if (int rc = conv_setup(&dd, x, x2, cin2, w_packed, bias, residual, y_head, a)) return rc;
@@ -206,6 +207,7 @@ extern "C" int fss_conv2d_dual_head_nhwc(const fss_conv_desc* d, const void* x, 
   a.y = y_head; a.y_ld = y_head_ld;
   a.w_head = w_head; a.bias_head = bias_head; a.cout_head = cout_head;
   if (d->in_dtype == FSS_F32_BF16X3) return dispatch_conv_head<f32s_t>(a, d->config, (hipStream_t)stream);
+  if (d->in_dtype == FSS_F16_W2) return dispatch_conv_head_wide(a, d->config, (hipStream_t)stream);
   return dispatch_conv_head<bf16_t>(a, d->config, (hipStream_t)stream);
 }
 

@@ -17,4 +17,8 @@ int dispatch_conv_half(ConvArgs& a, int in_dtype, int out_dtype, int config, hip
   return 2;
 }
 
+int dispatch_conv_head_wide(ConvArgs& a, int config, hipStream_t stream) {
+  return dispatch_conv_head<f16w_t>(a, config, stream);
+}
+
 }  // namespace fss

@@ -135,7 +135,6 @@ conv_igemm_kernel(const ConvArgs a) {
   // remainders (k_pad elements further along the packed row); every MFMA step runs once per part
   constexpr bool WIDE = std::is_same<T, f16w_t>::value;
   constexpr int BPL = WIDE ? 2 : 1;
-  static_assert(!(WIDE && HEAD), "no classifier-head form of the two-part weight mode");
   constexpr int LOADS = A_IT + BPL * B_IT;  // DMA pieces per wave per stage
   constexpr int RSTEP = NT / CPR;           // row step between a thread's chunks
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -460,7 +459,10 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NI; ++j) MMA::run(acc[i][j], fa[i], fl[j]);    // the small terms first
+          for (int j = 0; j < NI; ++j) {                                       // the small terms first
+            if constexpr (HEAD) MMA::run(acc[i][j], fl[j], fa[i]);
+            else MMA::run(acc[i][j], fa[i], fl[j]);
+          }
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -484,8 +486,10 @@ conv_igemm_kernel(const ConvArgs a) {
     // Split mode: residuals are float (two 16-byte loads per 8 channels), the activated values
     // are split like every other activation and the classifier weights arrive as two bf16
     // planes [32][cout] (high parts, then remainders): three MFMAs per step again.
-    constexpr bool SPLIT = MMA::PAIRED;
-    constexpr unsigned ESZ = (unsigned)sizeof(T);
+    // (the same epilogue serves half-precision activations against two-f16 weights: its residuals,
+    // interpolation sources and second product are those of the split mode)
+    constexpr bool SPLIT = MMA::PAIRED || WIDE;
+    constexpr unsigned ESZ = SPLIT ? 4u : (unsigned)sizeof(T);     // bytes per residual element
     // 8 consecutive channels as they lie in memory, and as floats
     struct Raw8 { uint4 a, b; };
     auto raw8 = [](const char* p) {
@@ -723,7 +727,7 @@ conv_igemm_kernel(const ConvArgs a) {
           uint4 fh, fl;
           split8(v8, fh, fl);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) MMA::run3(acc2[i][ct], wa[ct], wal[ct], fh, fl);
+          for (int ct = 0; ct < 2; ++ct) Mma<f32s_t, 16>::run3(acc2[i][ct], wa[ct], wal[ct], fh, fl);
         } else {
           const uint4 fb = make_uint4(pack_bf16x2(v8[0], v8[1]), pack_bf16x2(v8[2], v8[3]),
                                       pack_bf16x2(v8[4], v8[5]), pack_bf16x2(v8[6], v8[7]));
@@ -1048,13 +1052,19 @@ static int dispatch_conv(ConvArgs& a, int config, hipStream_t stream) {
 // in_dtype FSS_F16 with out_dtype FSS_F16 / FSS_F32_BF16X3 / FSS_F32, or in_dtype FSS_F32_BF16X3
 // with out_dtype FSS_F16.
 int dispatch_conv_half(ConvArgs& a, int in_dtype, int out_dtype, int config, hipStream_t stream);
+// ... and the classifier-head form for FSS_F16_W2 input
+int dispatch_conv_head_wide(ConvArgs& a, int config, hipStream_t stream);
 
 // Classifier-head form: the 16x16x32 configurations whose N tile holds every output channel
 // of the layer (BN >= 128 and cout <= BN); -1 = this configuration cannot.
 template <typename T, int BM, int BN, int WM, int WN, int BKB, int NS, int FM>
 static int launch_conv_head(ConvArgs& a, hipStream_t stream) {
-  // split mode: only the configurations with an even number of k steps per tile
-  if constexpr (FM == 16 && BN >= 128 && (std::is_same<T, bf16_t>::value || (BKB / 64) % 2 == 0)) {
+  // split mode: only the configurations with an even number of k steps per tile; two-f16
+  // weights: only those whose ring fits the LDS with two weight tiles per stage
+  constexpr bool kFits = std::is_same<T, bf16_t>::value ||
+                         (std::is_same<T, f32s_t>::value && (BKB / 64) % 2 == 0) ||
+                         (std::is_same<T, f16w_t>::value && NS * (BM + 2 * BN) * BKB < 160 * 1024);
+  if constexpr (FM == 16 && BN >= 128 && kFits) {
     if (a.Cout > BN) return -1;
     return launch_conv_impl<T, float, BM, BN, WM, WN, BKB, NS, FM, true, true>(a, stream);
   } else {
@@ -1064,7 +1074,10 @@ static int launch_conv_head(ConvArgs& a, hipStream_t stream) {
 
 template <typename T>
 static int dispatch_conv_head(ConvArgs& a, int config, hipStream_t stream) {
-  if (config == 0) config = a.Cout > 128 ? 28 : 29;
+  if (config == 0) {
+    if (std::is_same<T, f16w_t>::value) config = a.Cout > 128 ? 27 : 31;
+    else config = a.Cout > 128 ? 28 : 29;
+  }
   if (config == kConv8Config) config = 28;
   int rc = -1;
   switch (config) {

@@ -63,8 +63,12 @@ DEFAULT_HALF_SCOPES = (r'/bottleneck_v1/conv2$', r'^Conv(_[123])?$')
 # where 11-bit weights in the same layers cost several times that.  The two convolutions that read
 # the max-pooled output of the first convolution (conv1 and the projection shortcut of the first
 # unit) take half-precision activations as well, so that the largest tensor of the backbone and
-# its pooled form are written and read at two bytes per element (rms logit error 2.25e-4).
-DEFAULT_HALF_ACT_SCOPES = (r'/bottleneck_v1/conv3$', r'/block1/unit_1/bottleneck_v1/(conv1|shortcut)$')
+# its pooled form are written and read at two bytes per element (rms logit error 2.25e-4).  The 1x1
+# convolution of a cascade feature fusion (architectures/icnet_architecture.py:243-247) reads its
+# branch the same way where nothing else needs that tensor at float quality - the full-resolution
+# branch in front of the last fusion (2.29e-4).
+DEFAULT_HALF_ACT_SCOPES = (r'/bottleneck_v1/conv3$', r'/block1/unit_1/bottleneck_v1/(conv1|shortcut)$',
+                           r'^CascadeFeatureFusion(_\d+)?/Conv$')
 
 
 def f32_to_bf16_bits(a):
@@ -405,6 +409,8 @@ class CompiledGraph(object):
                     mate = other
         if mate is None:
             return ln not in self.dual
+        if mate.pos < ln.pos and self._zoom_source(mate) is not None:
+            return True     # the mate runs in front of its zoom, in launches of its own
         ms = mate.attrs['weights'].rsplit('/', 1)[0]
         return (any(r.search(ms) for r in self.half_act_re) and not self._is_half_conv(mate)
                 and (mate.attrs['kh'], mate.attrs['kw'], mate.attrs['rate']) == (1, 1, 1)
@@ -741,13 +747,13 @@ class CompiledGraph(object):
                    flops=2 * m * cout * (k + cout2),
                    nbytes=(m * (k + cout * (2 if res is not None else 1) + cout2) + cout * (k + cout2)) * 2)
 
-    def _head_partner(self, result, cout, dt):
+    def _head_partner(self, result, cout, dt, wide=False):
         """The 1x1 classifier (a convolution with biases, no normalisation or activation, at
         most 20 classes) that is the only consumer of `result`, when it can run in the
         epilogue of the convolution producing `result` (fss_conv2d_dual_head_nhwc)."""
         if not self.fuse_head or self.mfma_edge != 16 or cout % 32 or cout > 256:
             return None
-        if dt not in ('bf16', 'f32s'):
+        if dt not in ('bf16', 'f32s') and not (wide and dt == 'f16'):
             return None
         c = self._only_consumer(result, 'conv2d')
         if c is None or c in self.dual or self._dual_partner(c) is not None:
@@ -765,7 +771,7 @@ class CompiledGraph(object):
         sc, bh = self._fold_bn(head.attrs, ncls)
         Wh = np.zeros((32, cout), np.float32)
         Wh[:ncls] = (self.weights[head.attrs['weights']].astype(np.float64) * sc).reshape(cout, ncls).T
-        esz = _ESZ[x.dt]
+        esz = 2 if x.dt == 'bf16' else 4      # bytes per element of the residuals and their sources
         if x.dt == 'bf16':
             wh_bits = f32_to_bf16_bits(Wh)
         else:
@@ -782,9 +788,9 @@ class CompiledGraph(object):
                   head.shape, 'f32', phys_c=pc_out)
         self.vals[head] = out
         self.fused.add(head)
-        nbytes = ((x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] + n * ho * wo * cin2 + cout * k
-                   + cout * ncls + (n * ho * wo * cout if res is not None else 0)
-                   + (sum(int(np.prod(v.shape)) for v in zres) if zres else 0)) * esz
+        nbytes = ((x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] + n * ho * wo * cin2) * _ESZ[x.dt]
+                  + (cout * k + cout * ncls + (n * ho * wo * cout if res is not None else 0)
+                     + (sum(int(np.prod(v.shape)) for v in zres) if zres else 0)) * esz
                   + n * ho * wo * ncls * 4)
         zptrs = (ctypes.c_void_p * 4)(*[v.ptr for v in zres]) if zres else None
         self._emit('conv', name + '+' + head.attrs['weights'].rsplit('/', 2)[-2],
@@ -794,7 +800,8 @@ class CompiledGraph(object):
                     zres[0].shape[1] if zres else 0, zres[0].shape[2] if zres else 0, whdev.data_ptr(),
                     bhdev.data_ptr(), ncls, out.ptr, out.ld, self.sh),
                    flops=2 * n * ho * wo * cout * (k + ncls), nbytes=nbytes, keep=(d, zptrs),
-                   graph_flops=2 * n * ho * wo * cout * ((graph_k or k) + ncls))
+                   graph_flops=2 * n * ho * wo * cout * ((graph_k or k) + ncls),
+                   mpp=2 if d.in_dtype == _lib.F16_W2 else 1)
 
     def _zoom_source(self, B):
         """The low-resolution node x when conv B is conv3x3, dilation 2, stride 1, SAME of a
@@ -808,6 +815,10 @@ class CompiledGraph(object):
             return None
         b, src = B.attrs, B.inputs[0]
         d = self.lazy.get(src)
+        if d is None and src.kind == 'resize' and src not in self.vals:
+            # asked before the zoom has been lowered (a decision about an earlier tensor that
+            # depends on it): every resize is deferred when its turn comes
+            d = ('resize', src.inputs[0], src.attrs['align_corners'])
         if not d or d[0] != 'resize' or not d[2] or src.is_output or len(src.consumers) != 1:
             return None
         if (b['kh'], b['kw'], b['stride'], b['rate'], b['pad_top'], b['pad_left']) != (3, 3, 1, 2, 2, 2):
@@ -839,11 +850,11 @@ class CompiledGraph(object):
         sB, bB = self._fold_bn(b, cout)
         sA, bA = self._fold_bn(A.attrs, cout)
 
-        def pack(Wt, k):
+        def pack(Wt, k, form=dt):
             k_pad, cout_pad = (k + 63) // 64 * 64, (cout + 255) // 256 * 256
             Wp = np.zeros((cout_pad, k_pad), np.float32)
             Wp[:cout, :k] = Wt
-            return self._pack(Wp, dt), k_pad, cout_pad
+            return self._pack(Wp, form), k_pad, cout_pad
 
         WB = (self.weights[b['weights']].astype(np.float64) * sB).transpose(3, 0, 1, 2).reshape(cout, -1)
         wB, k_pad, cout_pad = pack(WB, 9 * cin)
@@ -888,14 +899,16 @@ class CompiledGraph(object):
                        nbytes=(n * h * w + n * ho * wo) * cout * esz)
             self.temps.append(r)
         # the 1x1 half, with the zoomed 3x3 half as its residual
+        # (a half-precision x2: read against two-f16 weights, FSS_F16_W2)
+        wide = x2.dt == 'f16'
         WA = (self.weights[A.attrs['weights']].astype(np.float64) * sA).reshape(cin2, cout).T
-        wA, k_pad2, _ = pack(WA, cin2)
+        wA, k_pad2, _ = pack(WA, cin2, 'f16w' if wide else dt)
         bdev = self._dev_f32(bA + bB)
         name = base + '+' + A.attrs['weights'].rsplit('/', 2)[-2]
         d = _lib.ConvDesc(n=n, h=ho, w=wo, cin=cin2, cout=cout, kh=1, kw=1, stride=1, dilation=1,
                           pad_top=0, pad_left=0, ho=ho, wo=wo, act=_lib.ACT_CODES[act],
-                          in_dtype=self._in_code(dt), out_dtype=_CODE[dt], y_ld=cout, res_ld=r.ld if r else 0,
-                          k_pad=k_pad2, cout_pad=cout_pad)
+                          in_dtype=_lib.F16_W2 if wide else self._in_code(dt), out_dtype=_CODE[dt], y_ld=cout,
+                          res_ld=r.ld if r else 0, k_pad=k_pad2, cout_pad=cout_pad)
         if head is not None:
             # the classifier launch interpolates the source-resolution results itself
             return self._emit_head(head, d, x2, None, 0, wA, bdev, cout, cin2, name, res=r,
@@ -907,15 +920,16 @@ class CompiledGraph(object):
         self._emit('conv', name, 'fss_conv2d_nhwc',
                    (ctypes.byref(d), x2.ptr, wA.data_ptr(), bdev.data_ptr(), r.ptr, out.ptr, self.sh),
                    flops=2 * n * ho * wo * cout * cin2,
-                   nbytes=(n * ho * wo * (cin2 + 2 * cout) + cout * cin2) * esz, keep=d,
-                   graph_flops=2 * n * ho * wo * cout * (9 * cin + cin2))
+                   nbytes=(n * ho * wo * 2 * cout + cout * cin2) * esz + n * ho * wo * cin2 * _ESZ[x2.dt], keep=d,
+                   graph_flops=2 * n * ho * wo * cout * (9 * cin + cin2), mpp=2 if wide else 1)
 
     def _l_conv_dual(self, A, B):
         """relu?(conv B + conv1x1 A) in one launch; A is the node being lowered."""
         low = self._zoom_source(B)
         if low is not None:
             xl, x2 = self._val(low), self._val(A.inputs[0])
-            if (xl.dense and x2.dense and xl.dt == x2.dt == self.dt and xl.phys_c == low.shape[3]
+            half2 = x2.dt == 'f16' and self._takes_half_acts(A)     # read with two-f16 weights
+            if (xl.dense and x2.dense and xl.dt == self.dt and (x2.dt == self.dt or half2) and xl.phys_c == low.shape[3]
                     and x2.phys_c == A.inputs[0].shape[3] and xl.phys_c % _EPC[xl.dt] == 0
                     and B.shape[3] % _EPC[xl.dt] == 0):
                 self.lazy.pop(B.inputs[0])

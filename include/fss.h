@@ -182,7 +182,9 @@ int fss_conv2d_dual_nhwc(const fss_conv_desc* desc, const void* x, const void* x
  * pixel leave the kernel (float32, pixel stride y_head_ld).  Replaces the last cascade
  * feature fusion + the `Predictions` slim.conv2d of architectures/icnet_architecture.py:
  * 131-142,238-252 (the classifier applied before the x2 upsampling, which commutes with a
- * 1x1 convolution).  desc->in_dtype FSS_BF16 (the rounding to bf16 in the formula above is
+ * 1x1 convolution).  desc->in_dtype FSS_F16_W2 behaves as FSS_F32_BF16X3 below with FSS_F16
+ * activations x, x2 and the two-f16 packed weights of that mode (residuals, w_head and the
+ * zoom sources as for FSS_F32_BF16X3).  desc->in_dtype FSS_BF16 (the rounding to bf16 in the formula above is
  * that mode's) or FSS_F32_BF16X3 (split-bfloat16 tensors, nothing rounded to 8 bits: the
  * activated values are split like every other activation); cin (and cin2) multiples of 64; cout a multiple
  * of 32 and <= 256; cout_head <= 20; w_head: bf16 [32][cout], rows >= cout_head zero

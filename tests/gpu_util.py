@@ -160,7 +160,8 @@ def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), ou
     + b_head through fss_conv2d_dual_head_nhwc (dt 'bf16': bfloat16 activations; 'f32x3': float
     tensors, split-bf16 products, nothing rounded to bfloat16); x2 / w2 may be None.
     Returns float32 [n,ho,wo,classes]."""
-    assert dt in ('bf16', 'f32x3')
+    assert dt in ('bf16', 'f32x3', 'f16w')
+    rdt = 'f32x3' if dt == 'f16w' else dt          # type of the residual
     n, h, wd, cin = x.shape
     kh, kw, _, cout = w.shape
     cin2 = x2.shape[3] if x2 is not None else 0
@@ -178,7 +179,8 @@ def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), ou
         wdev = torch.from_numpy(f32_to_bf16_bits(wp).view(np.int16)).cuda()
         wh_bits = f32_to_bf16_bits(wh)
     else:
-        wdev = torch.from_numpy(f32_split_bf16_rows(wp).view(np.int16)).cuda()
+        rows = f32_split_f16_rows if dt == 'f16w' else f32_split_bf16_rows
+        wdev = torch.from_numpy(rows(wp).view(np.int16)).cuda()
         hi = f32_to_bf16_bits(wh)
         wh_bits = np.concatenate([hi, f32_to_bf16_bits(wh - (hi.astype(np.uint32) << 16).view(np.float32))])
     whdev = torch.from_numpy(np.ascontiguousarray(wh_bits).view(np.int16)).cuda()
@@ -186,16 +188,16 @@ def conv2d_dual_head(x, w, x2, w2, bias, w_head, b_head, rate=1, pads=(0, 0), ou
     x2d = to_dev(x2, dt) if cin2 else None
     bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda()
     bh = torch.from_numpy(np.asarray(b_head, np.float32)).cuda()
-    rd = to_dev(residual, dt) if residual is not None else None
+    rd = to_dev(residual, rdt) if residual is not None else None
     # the interpolated sources of the split mode are plain float tensors
-    zd = [to_dev(t, 'f32' if dt == 'f32x3' else dt) for t in zoom_residual] if zoom_residual is not None else None
+    zd = [to_dev(t, 'f32' if dt != 'bf16' else dt) for t in zoom_residual] if zoom_residual is not None else None
     zp = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in zd]) if zd else None
     zh, zw = (zd[0].shape[1], zd[0].shape[2]) if zd else (0, 0)
     ld = y_ld or ncls
     y = torch.full((n, ho, wo, ld), -77.0, dtype=torch.float32, device='cuda')
     d = _lib.ConvDesc(n=n, h=h, w=wd, cin=cin, cout=cout, kh=kh, kw=kw, stride=1,
                       dilation=rate, pad_top=pads[0], pad_left=pads[1], ho=ho, wo=wo,
-                      act=_lib.ACT_CODES[act], in_dtype=conv_in_code(dt), out_dtype=DT[dt][0],
+                      act=_lib.ACT_CODES[act], in_dtype=conv_in_code(dt), out_dtype=DT[rdt][0],
                       y_ld=cout, res_ld=cout, k_pad=k_pad, cout_pad=cout_pad, config=config)
     torch.cuda.synchronize()
     _lib.call('fss_conv2d_dual_head_nhwc', ctypes.byref(d), xd.data_ptr(),

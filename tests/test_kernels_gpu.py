@@ -361,7 +361,7 @@ def test_dilated_conv_of_a_zoom_at_the_source_resolution(shape, dt):
             _close(out[sl], ref[sl], 2e-5, 'border')
 
 
-@pytest.mark.parametrize('dt', ['bf16', 'f32x3'])
+@pytest.mark.parametrize('dt', ['bf16', 'f32x3', 'f16w'])
 @pytest.mark.parametrize('n,zh,zw,cout', [(2, 6, 9, 128), (3, 4, 4, 128), (3, 9, 40, 256), (2, 5, 70, 128)])
 def test_head_conv_interpolates_its_residual_from_the_source_resolution(n, zh, zw, cout, dt):
     """fss_conv2d_dual_head_nhwc with zoom_residual = {y, ytb, ylr, ycn}: the epilogue adds the
@@ -377,6 +377,8 @@ def test_head_conv_interpolates_its_residual_from_the_source_resolution(n, zh, z
     rnd = gu.bf16_round if dt == 'bf16' else (lambda v: v)
     r16 = lambda *shape: rnd(rng.normal(0, 1, shape).astype(np.float32))
     x, w = r16(n, h, wd, cin), rnd(rng.normal(0, 0.1, (1, 1, cin, cout)).astype(np.float32))
+    if dt == 'f16w':        # half-precision activations, weights of float quality
+        x = gu.f16_round(x)
     y, ytb, ylr, ycn = r16(n, zh, zw, cout), r16(2 * n, 1, zw, cout), r16(2 * n, zh, 1, cout), r16(4 * n, 1, 1, cout)
     bias = rng.normal(0, 1, cout).astype(np.float32)
     w_head = rnd(rng.normal(0, 0.1, (cout, ncls)).astype(np.float32))
@@ -411,7 +413,7 @@ def test_head_conv_interpolates_its_residual_from_the_source_resolution(n, zh, z
         _close(out, ref, 2e-2, 'head conv with zoomed residual')
         assert np.mean(np.abs(out - ref) > 5e-3) < 0.01
     else:
-        _close(out, ref, 2e-4, 'float32x3 head conv with zoomed residual')
+        _close(out, ref, 2e-4, '%s head conv with zoomed residual' % dt)
 
 
 def test_entry_points_reject_bad_arguments():
