@@ -471,7 +471,7 @@ def test_entry_points_reject_bad_arguments():
     assert 'zoom_residual' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
     bad = list(head); bad[9] = None
     assert 'null' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(good), *bad)
-    assert 'bf16' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(desc(in_dtype=L.F32, out_dtype=L.F32)),
+    assert 'FSS_BF16' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(desc(in_dtype=L.F32, out_dtype=L.F32)),
                               *head)
     assert '16x16x32' in rejected('fss_conv2d_dual_head_nhwc', ctypes.byref(desc(config=1)), *head)
     # fused stem pair: only bfloat16, 32 or 64 channels
