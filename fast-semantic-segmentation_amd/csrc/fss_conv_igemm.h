@@ -818,6 +818,24 @@ conv_igemm_kernel(const ConvArgs a) {
   constexpr int TPS = SLABR / FM;            // MFMA tile rows per slab
 #pragma unroll
   for (int sl = 0; sl < SLABS; ++sl) {
+    // split-bfloat16 residual of this slab's pieces: requested before the slab is staged, so
+    // that the loads of all passes are in flight together and behind the LDS traffic (clamped
+    // addresses: a piece past the end of the tensor reads a valid one and is never stored)
+    constexpr bool RES_SLAB = std::is_same<TR, f32s_t>::value && VW == 8;
+    uint4 rs[RES_SLAB ? PASSES : 1][2];
+    if constexpr (RES_SLAB) {
+      if (rg != nullptr && vec_ok) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+          const int g = lane + p * 64;
+          const int m = min(tile_m * BM + wm * WTM + sl * SLABR + g / QPR, a.M - 1);
+          const int n = min(n_base + (g % QPR) * VW, a.Cout - VW);
+          const uint4* rq = reinterpret_cast<const uint4*>(rg + (size_t)m * a.res_ld + n);
+          rs[p][0] = rq[0];
+          rs[p][1] = rq[1];
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int n = n_base + j * FM + lrow;
@@ -847,9 +865,8 @@ conv_igemm_kernel(const ConvArgs a) {
           if (rg != nullptr) {
             if constexpr (std::is_same<TR, f32s_t>::value) {
               if constexpr (VW == 8) {
-                const uint4* rq = reinterpret_cast<const uint4*>(rg + (size_t)m * a.res_ld + n);
                 float r8[8];
-                join8(rq[0], rq[1], r8);
+                join8(rs[p][0], rs[p][1], r8);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] += r8[q];
               } else {
