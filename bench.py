@@ -389,7 +389,9 @@ def main():
                    'compute_mode': args.dtype,
                    'parallelism': 'frames sharded over %d GPU(s)' % world,
                    'streams': cg.stream_choice,
-                   'device_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1)},
+                   'device_memory_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1),
+                   'activation_gb': round(cg.activation_bytes / 1e9, 1),
+                   'activation_gb_without_sharing': round(cg.activation_bytes_unshared / 1e9, 1)},
         'roofline': roofline_of(prof, args.dtype, B),
         'hbm_kernels': {'ms_per_step': other_ms,
                         'achieved_gbps': other_bytes / (other_ms * 1e-3) / 1e9 if other_ms > 0 else None,

@@ -212,7 +212,7 @@ class CompiledGraph(object):
                  commute_classifier=True, use_hip_graph=True, autotune=True, mfma_edge=None,
                  fuse_stem=True, streams=2, fuse_pyramid_pool=True, fuse_stem2=True, fuse_dual=True, fuse_chain=True, commute_pyramid=None, resident_3x3=True,
                  fuse_head=True, collapse_zooms=True, commute_zoom=None, fuse_zoom_residual=None,
-                 ksplit=False, half_scopes=None, half_act_scopes=None):
+                 ksplit=False, half_scopes=None, half_act_scopes=None, reuse_buffers=None):
         if not torch.cuda.is_available():
             raise RuntimeError('fss.plan needs a ROCm GPU; there is no CPU execution path')
         # 'float32x3': float32 tensors everywhere; the convolutions form their products on the
@@ -277,8 +277,18 @@ class CompiledGraph(object):
         self.stream_choice = 'single: not requested'
         self.events = []
         self.tuned_now = 0      # layer shapes timed by this plan (0: all came from the table)
+        # Activation memory: tensors whose lifetimes (first to last launch that touches them) do
+        # not overlap share device memory.  Off: every tensor has a buffer of its own.
+        self.reuse_buffers = (os.environ.get('FSS_REUSE_BUFFERS', '1') != '0'
+                              if reuse_buffers is None else reuse_buffers)
+        self._allocs = []       # tensors handed out by _alloc, in call order
+        self._mem_plan = None   # per _alloc call: (bytes, first step, last step, stream, shareable)
+        self._blocks = []       # device blocks behind the shared tensors: [tensor, tenant's last step, stream]
+        self.activation_bytes = self.activation_bytes_unshared = 0
         with torch.cuda.device(self.device):
             self._import(graph, outputs, commute_classifier)
+            if self.reuse_buffers:
+                self._plan_memory(streams > 1 and use_hip_graph)
             self._lower()
             self._dependencies()                  # every pointer of every launch must resolve
             torch.cuda.synchronize(self.device)   # constants were uploaded on torch's stream
@@ -354,9 +364,101 @@ class CompiledGraph(object):
 
     # ------------------------------------------------------------------ utils
     def _alloc(self, shape, dt, phys_c=None):
+        """Device tensor [n,h,w,phys_c] of an activation.  With a memory plan (second lowering
+        pass) a tensor whose lifetime is known may take over the block of one that is dead by
+        the time of its first launch; the block then counts as ONE buffer in the dependency
+        analysis, so write-after-read and write-after-write between its tenants are ordered like
+        any other hazard."""
         n, h, w, c = shape
-        return torch.empty((n, h, w, phys_c if phys_c is not None else c),
-                           dtype=_TORCH_DT[dt], device=self.device)
+        full = (n, h, w, phys_c if phys_c is not None else c)
+        tdt = _TORCH_DT[dt]
+        k = len(self._allocs)
+        if self._mem_plan is None:
+            t = torch.empty(full, dtype=tdt, device=self.device)
+            self._allocs.append(t)
+            return t
+        nbytes, first, last, stream, shareable = self._mem_plan[k]
+        need = int(np.prod(full)) * torch.empty((), dtype=tdt).element_size()
+        if need != nbytes:
+            raise RuntimeError('the second lowering pass asks for other buffers than the first')
+        self.activation_bytes_unshared += need
+        blk = None
+        if shareable:
+            # the smallest free block that holds it and is at most twice its size
+            best = None
+            for b in self._blocks:
+                if b[2] == stream and b[1] < first and need <= b[0].numel() <= 2 * need:
+                    if best is None or b[0].numel() < best[0].numel():
+                        best = b
+            if best is not None:
+                best[1] = last
+                blk = best[0]
+        if blk is None:
+            blk = torch.empty((max(need, 1) + 255) // 256 * 256, dtype=torch.uint8, device=self.device)
+            self.activation_bytes += blk.numel()
+            self._blocks.append([blk, last if shareable else 1 << 60, stream])
+        t = blk[:need].view(tdt).view(full)
+        self._allocs.append(t)
+        return t
+
+    def _reset_lowering(self):
+        self.steps, self.step_fname = [], []
+        self.vals, self.lazy, self.dual = {}, {}, {}
+        self.keepalive, self.temps, self.workspaces = [], [], []
+        self.input_val = None
+        self.param_bytes = 0
+        self._allocs = []
+
+    def _plan_memory(self, two_streams):
+        """First lowering pass: every activation in a buffer of its own, nothing launched.  The
+        launches it emits say which of them touch which buffer - the ground truth whatever was
+        fused, deferred or aliased on the way - hence every buffer's first and last launch and
+        the stream(s) it is used on.  A buffer may later share memory only if it is no output,
+        is touched by at least one launch, and only by launches of one stream."""
+        self._lower()
+        allocs = self._allocs
+        starts = sorted((t.data_ptr(), k) for k, t in enumerate(allocs))
+        first = [None] * len(allocs)
+        last = [None] * len(allocs)
+        streams = [set() for _ in allocs]
+        if two_streams and self._assign_streams(None):
+            step_stream = [st.stream for st in self.steps]
+        else:
+            step_stream = [0] * len(self.steps)
+        keys = [a for a, _ in starts]
+        for i, (st, fname) in enumerate(zip(self.steps, self.step_fname)):
+            argtypes = _lib.PROTOTYPES[fname][1]
+            for ai, arg in enumerate(st.args[:-1]):
+                if isinstance(arg, ctypes.Array) and getattr(arg, '_type_', None) is ctypes.c_void_p:
+                    ptrs = [q for q in arg if q]
+                elif argtypes[ai] is ctypes.c_void_p and isinstance(arg, int) and arg:
+                    ptrs = [arg]
+                else:
+                    continue
+                for q in ptrs:
+                    j = bisect.bisect_right(keys, q) - 1
+                    if j < 0:
+                        continue
+                    k = starts[j][1]
+                    t = allocs[k]
+                    if q < t.data_ptr() + t.numel() * t.element_size():
+                        first[k] = i if first[k] is None else first[k]
+                        last[k] = i
+                        streams[k].add(step_stream[i])
+        pinned = {self.vals[ln].buf.data_ptr() for ln in self.out_nodes.values() if ln in self.vals}
+        plan = []
+        for k, t in enumerate(allocs):
+            ok = first[k] is not None and len(streams[k]) == 1 and t.data_ptr() not in pinned
+            plan.append((t.numel() * t.element_size(), first[k] if ok else 0, last[k] if ok else 1 << 60,
+                         min(streams[k]) if streams[k] else 0, ok))
+        for e in self.events:
+            lib.fss_event_destroy(e)
+        self.events = []
+        self._reset_lowering()
+        del allocs, starts
+        torch.cuda.synchronize(self.device)
+        torch.cuda.empty_cache()
+        self._mem_plan = plan
 
     def _in_code(self, dt):
         """in_dtype code of a convolution whose input is stored as `dt`."""
@@ -1613,7 +1715,9 @@ class CompiledGraph(object):
             out.sort()
             return out, [r[0] for r in out]
 
-        ranges, starts = spans([v.buf for v in list(self.vals.values()) + self.temps + [self.input_val]]
+        # (shared blocks first: a block is one buffer whoever its tenants are)
+        ranges, starts = spans([b[0] for b in self._blocks]
+                               + [v.buf for v in list(self.vals.values()) + self.temps + [self.input_val]]
                                + self.workspaces)
         consts, cstarts = spans(self.keepalive)
 

@@ -105,7 +105,7 @@ def _scores_of(cg):
     a = cg.steps[i].args
     ptr, n, h, w, c, ld = a[0], a[3], a[4], a[5], a[6], a[7]
     for v in cg.vals.values():
-        if v.buf.data_ptr() == ptr:
+        if v.buf.data_ptr() == ptr and v.buf.numel() == n * h * w * ld:     # (dead tensors may share its memory)
             cg.sync()
             torch.cuda.synchronize()
             return v.buf.reshape(n, h, w, ld)[..., :c].float().cpu().numpy()

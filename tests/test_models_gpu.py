@@ -551,3 +551,33 @@ def test_icnet_pretrain_single_branch_mode(dtype, tol):
     assert err <= tol
     if dtype != 'bfloat16':
         assert agree >= 0.999
+
+
+@pytest.mark.parametrize('dtype', ['mixed', 'bfloat16'])
+def test_shared_activation_memory_changes_nothing(dtype):
+    """Tensors with disjoint lifetimes share device memory (the lifetimes are read off the
+    launches of a first lowering pass): same bits as the plan with a buffer per tensor, for the
+    logits and the labels, on the two-stream graph and on eager replays, in less memory."""
+    from fss import plan
+    case = CASES[0]
+    arch, ext, fs, pf, in_shape, pad_shape = case
+    g, cfg, outs, weights = build(arch, ext, fs, pf, (8,) + tuple(in_shape[1:]), pad_shape)
+    img = np.random.default_rng(3).integers(0, 256, (8,) + tuple(in_shape[1:])).astype(np.uint8)
+    ref = plan.CompiledGraph(g, outs, weights, dtype=dtype, reuse_buffers=False)
+    want = ref.run(img)
+    assert ref.activation_bytes == 0
+    del ref
+    cg = plan.CompiledGraph(g, outs, weights, dtype=dtype, reuse_buffers=True)
+    got = cg.run(img)
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    assert 0 < cg.activation_bytes < 0.7 * cg.activation_bytes_unshared
+    for _ in range(2):          # replays, and the launch-by-launch path
+        cg.launch()
+    cg.sync()
+    assert np.array_equal(cg.fetch(outs[0]), want[0])
+    cg.run_eager()
+    cg.sync()
+    assert np.array_equal(cg.fetch(outs[1]), want[1])
+    # a side chain survives the sharing: its buffers are shared among its own launches only
+    assert any(s.stream == 1 for s in cg.steps) or not cg.stream_choice.startswith('two')
