@@ -265,9 +265,16 @@ template <> struct Chunk<f16_t> {
       v[2 * i + 1] = Half16<f16_t>::hi(w[i]);
     }
   }
+  // (saturating, like every half-precision store of the library)
+  static __device__ __forceinline__ unsigned sat2(float a, float b) {
+    return Half16<f16_t>::pack2(__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f),
+                                __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f));
+  }
+  __device__ __forceinline__ void store(f16_t* p) const {
+    *reinterpret_cast<uint4*>(p) = make_uint4(sat2(v[0], v[1]), sat2(v[2], v[3]), sat2(v[4], v[5]), sat2(v[6], v[7]));
+  }
   __device__ __forceinline__ void store_nt(f16_t* p) const {
-    typedef Half16<f16_t> H;
-    store16_nt(p, H::pack2(v[0], v[1]), H::pack2(v[2], v[3]), H::pack2(v[4], v[5]), H::pack2(v[6], v[7]));
+    store16_nt(p, sat2(v[0], v[1]), sat2(v[2], v[3]), sat2(v[4], v[5]), sat2(v[6], v[7]));
   }
 };
 // bytes of a channel chunk of T (what the copy kernels move per thread)

@@ -1473,7 +1473,7 @@ int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y,
                       int wd, int c, int kh, int kw, int stride, int dilation, int pad_top,
                       int pad_left, int ho, int wo, int act, int dtype, void* stream) {
   FSS_REQUIRE(x && w && y, "null argument");
-  FSS_DTYPE_OK(dtype);
+  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_BF16 || dtype == FSS_F32_BF16X3 || dtype == FSS_F16, "bad dtype");
   FSS_CHUNK_OK(c, dtype);
   FSS_ALIGNED(x); FSS_ALIGNED(y);
   FSS_REQUIRE(n > 0 && h > 0 && wd > 0 && ho > 0 && wo > 0, "bad shape");
@@ -1496,7 +1496,8 @@ int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y,
   else if (stride == 2 && dilation == 1) { FSS_DW(T, 2, 1); }          \
   else handled = false;
     bool handled = true;
-    if (dtype == FSS_F32) { FSS_DW_ANY(float) } else if (dtype == FSS_F32_BF16X3) { FSS_DW_ANY(f32s_t) } else { FSS_DW_ANY(bf16_t) }
+    if (dtype == FSS_F32) { FSS_DW_ANY(float) } else if (dtype == FSS_F32_BF16X3) { FSS_DW_ANY(f32s_t) }
+    else if (dtype == FSS_F16) { FSS_DW_ANY(f16_t) } else { FSS_DW_ANY(bf16_t) }
 #undef FSS_DW_ANY
 #undef FSS_DW
     if (handled) {
@@ -1512,6 +1513,10 @@ int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y,
   else if (dtype == FSS_F32_BF16X3)
     hipLaunchKernelGGL(dwconv_kernel<f32s_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
                        (const f32s_t*)x, w, bias, (f32s_t*)y, n, h, wd, c, kh, kw, stride, dilation,
+                       pad_top, pad_left, ho, wo, act);
+  else if (dtype == FSS_F16)
+    hipLaunchKernelGGL(dwconv_kernel<f16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                       (const f16_t*)x, w, bias, (f16_t*)y, n, h, wd, c, kh, kw, stride, dilation,
                        pad_top, pad_left, ho, wo, act);
   else
     hipLaunchKernelGGL(dwconv_kernel<bf16_t>, dim3(grid_for(total)), dim3(kBlock), 0, s,

@@ -246,7 +246,8 @@ class CompiledGraph(ConvLowering, ConvTuning, Schedule):
         if not any(r.search(scope) for r in self.half_act_re):
             return False
         if ((a['kh'], a['kw'], a['stride'], a['rate'], a['pad_top'], a['pad_left']) != (1, 1, 1, 1, 0, 0)
-                or a['biases'] is not None or ln.inputs[0].shape[3] % 64 or ln.shape[:3] != ln.inputs[0].shape[:3]):
+                or a['biases'] is not None or ln.inputs[0].shape[3] % 8 or ln.shape[3] % 8
+                or ln.shape[:3] != ln.inputs[0].shape[:3]):
             return False
         if not self.fuse_dual:
             return True
@@ -260,6 +261,8 @@ class CompiledGraph(ConvLowering, ConvTuning, Schedule):
                     mate = other
         if mate is None:
             return ln not in self.dual
+        if ln.inputs[0].shape[3] % 64:
+            return False    # a shared launch takes whole K tiles of both inputs
         if mate.pos < ln.pos and self._zoom_source(mate) is not None:
             return True     # the mate runs in front of its zoom, in launches of its own
         ms = mate.attrs['weights'].rsplit('/', 1)[0]
@@ -280,6 +283,8 @@ class CompiledGraph(ConvLowering, ConvTuning, Schedule):
                 continue
             if c.kind == 'max_pool' and c.attrs['k'] > 1 and not c.is_output and self._store_dt(c, in_dt) == 'f16':
                 continue        # the largest of half-precision numbers is one of them
+            if c.kind == 'depthwise' and not c.is_output and self._store_dt(c, in_dt) == 'f16':
+                continue        # float arithmetic on either side: only the two stores round
             if c.kind == 'add' and len(c.inputs) == 2:
                 # a residual: the half-precision convolution that absorbs the add reads it in the
                 # type it stores its own result in
@@ -397,6 +402,7 @@ class CompiledGraph(ConvLowering, ConvTuning, Schedule):
         wdev = self._dev_f32(Wt.reshape(a['kh'] * a['kw'], c))
         bdev = self._dev_f32(bias)
         self.param_bytes += a['kh'] * a['kw'] * c * 4
+        # (a half-precision input means that every reader of the output takes half precision too)
         out = Val(self._alloc(ln.shape, x.dt), ln.shape, x.dt)
         self.vals[ln] = out
         self._emit('depthwise', a['weights'].rsplit('/', 1)[0], 'fss_dwconv2d_nhwc',

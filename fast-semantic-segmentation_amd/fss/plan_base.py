@@ -36,9 +36,12 @@ DEFAULT_HALF_SCOPES = (r'/bottleneck_v1/conv2$', r'^Conv(_[123])?$')
 # its pooled form are written and read at two bytes per element (rms logit error 2.25e-4).  The 1x1
 # convolution of a cascade feature fusion (architectures/icnet_architecture.py:243-247) reads its
 # branch the same way where nothing else needs that tensor at float quality - the full-resolution
-# branch in front of the last fusion (2.29e-4).
+# branch in front of the last fusion (2.29e-4).  In MobileNetV2 the projection of an inverted
+# residual (third_party/conv_blocks.py:290-300) reads the depthwise output this way, and the
+# expanded tensors on both sides of the depthwise convolution - internal to the unit, six times
+# as wide as its input - are half precision (ICNet-MobileNetV2: 3.51e-4 -> 3.71e-4).
 DEFAULT_HALF_ACT_SCOPES = (r'/bottleneck_v1/conv3$', r'/block1/unit_1/bottleneck_v1/(conv1|shortcut)$',
-                           r'^CascadeFeatureFusion(_\d+)?/Conv$')
+                           r'^CascadeFeatureFusion(_\d+)?/Conv$', r'/expanded_conv(_\d+)?/project$')
 
 
 class LNode(object):

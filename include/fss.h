@@ -260,7 +260,8 @@ int fss_zoom2_conv_commute(const void* y, const void* ytb, const void* ylr, cons
 
 /* Depthwise 3x3-style convolution + bias + activation.
  * Replaces slim.separable_conv2d(num_outputs=None) + batch_norm + relu6
- * (third_party/conv_blocks.py:240-249,280).  w: float [kh*kw][c] (BN folded). */
+ * (third_party/conv_blocks.py:240-249,280).  w: float [kh*kw][c] (BN folded).  dtype may
+ * also be FSS_F16 (float arithmetic, half-precision tensors). */
 int fss_dwconv2d_nhwc(const void* x, const float* w, const float* bias, void* y,
                       int n, int h, int wd, int c, int kh, int kw, int stride,
                       int dilation, int pad_top, int pad_left, int ho, int wo,
