@@ -303,7 +303,7 @@ def pack_stem_weights(w, dt, mean=None, scale=None):
     assert cin == 3
     k_pad, cout_pad = ctypes.c_int(0), ctypes.c_int(0)
     _lib.call('fss_stem_pack_dims', kh, kw, cout, conv_in_code(dt), ctypes.byref(k_pad), ctypes.byref(cout_pad))
-    if dt == 'f32x3':
+    if dt in ('f32x3', 'f16w'):
         from fss import plan
         return torch.from_numpy(plan.stem_pack_f16x2(w, mean, scale, cout_pad.value, k_pad.value).view(np.int16)).cuda()
     wp = np.zeros((cout_pad.value, k_pad.value), np.float32)

@@ -239,3 +239,54 @@ def test_conv2d_wide_weights_epilogue_and_configurations():
     for cfg in (0, 14, 27):
         out = gu.conv2d_dual(x, w, x2, w2, bias, 1, 1, (0, 0), (h, wd), 'relu', 'f16w', config=cfg, out_dt='f32x3')
         _close(out, ref2, 2e-5, 'two-input two-f16-weight conv, config %d' % cfg)
+
+
+def test_maxpool_and_depthwise_half():
+    """fss_maxpool_nhwc (exact: selection only) and fss_dwconv2d_nhwc (float arithmetic, one
+    rounding of the result) on half-precision tensors, both depthwise kernels."""
+    import torch
+    gu, L = _gu(), _lib()
+    rng = np.random.default_rng(14)
+    x = gu.f16_round(rng.normal(0, 1, (2, 37, 41, 64)).astype(np.float32))
+    ho, pt, _ = O.same_padding(37, 3, 2)
+    wo, pl, _ = O.same_padding(41, 3, 2)
+    y = torch.empty((2, ho, wo, 64), dtype=torch.float16, device='cuda')
+    L.call('fss_maxpool_nhwc', gu.to_dev(x, 'f16').data_ptr(), y.data_ptr(), 2, 37, 41, 64, 3, 2, pt, pl, ho, wo,
+           L.F16, None)
+    assert np.array_equal(gu.to_host(y), O.max_pool_same(x, 3, 2))
+    for (n, h, wd, c, stride, rate) in [(8, 129, 257, 96, 1, 4), (12, 200, 258, 64, 2, 1), (2, 20, 26, 24, 2, 1),
+                                        (1, 15, 22, 16, 1, 3)]:
+        x = gu.f16_round(rng.normal(0, 1, (n, h, wd, c)).astype(np.float32))
+        w = rng.normal(0, 0.4, (3, 3, c, 1)).astype(np.float32)
+        bias = rng.normal(0, 0.5, c).astype(np.float32)
+        ref = O.relu6(O.depthwise_conv2d(x, w, stride, rate, np.float64) + bias)
+        ho, pt, _ = O.same_padding(h, 3, stride, rate)
+        wo, pl, _ = O.same_padding(wd, 3, stride, rate)
+        wdv = torch.from_numpy(w[:, :, :, 0].reshape(9, c).copy()).cuda()
+        bd = torch.from_numpy(bias).cuda()
+        y = torch.empty((n, ho, wo, c), dtype=torch.float16, device='cuda')
+        L.call('fss_dwconv2d_nhwc', gu.to_dev(x, 'f16').data_ptr(), wdv.data_ptr(), bd.data_ptr(), y.data_ptr(),
+               n, h, wd, c, 3, 3, stride, rate, pt, pl, ho, wo, L.ACT_RELU6, L.F16, None)
+        _close(gu.to_host(y), ref, 1.0 / 1024, 'half-precision depthwise %s' % ((n, h, wd, c, stride, rate),))
+
+
+@pytest.mark.parametrize('k,stride,cout,sub', [(7, 2, 64, 2), (3, 2, 32, 1), (3, 1, 24, 1)])
+def test_stem_conv_u8_raw_bytes_half_output(k, stride, cout, sub):
+    """fss_stem_conv_u8 with dtype FSS_F16_W2: the raw frame bytes against two-f16 weights (mean
+    and scale folded into them) with half-precision output - one rounding of the result away
+    from the float64 oracle, borders of the padded image included."""
+    gu = _gu()
+    rng = np.random.default_rng(15)
+    frames = rng.integers(0, 256, (2, 45, 77, 3)).astype(np.uint8)
+    hp, wp = 47, 80
+    mean, scale = (123.68, 116.779, 103.939), (1.0, 0.5, 2.0 / 255)
+    w = rng.normal(0, 0.05, (k, k, 3, cout)).astype(np.float32)
+    bias = rng.normal(0, 0.5, cout).astype(np.float32)
+    img = (O.pad_to_bounding_box(frames.astype(np.float64), hp, wp) - np.asarray(mean)) * np.asarray(scale)
+    img = img[:, ::sub, ::sub]
+    hl, wl = img.shape[1:3]
+    ho, pt, pb = O.same_padding(hl, k, stride, 1)
+    wo, pl, pr = O.same_padding(wl, k, stride, 1)
+    ref = O.relu6(O.conv2d(img, w, stride, 1, (pt, pb, pl, pr), np.float64) + bias)
+    got = gu.stem_conv(frames, w, bias, mean, scale, sub, (hl, wl), stride, 1, (pt, pl), (ho, wo), 'relu6', 'f16w')
+    _close(got, ref, 1.0 / 1024, 'raw-byte stem, half output')
