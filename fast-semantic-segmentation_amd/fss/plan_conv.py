@@ -176,7 +176,10 @@ class ConvLowering(object):
                 or b['activation'] is not None or A.shape != ln.shape):
             return None
         if ln.inputs[0].shape[3] % 64 or A.inputs[0].shape[3] % 64:
-            return None
+            # whole K tiles of both inputs - unless `ln` runs in front of its zoom, in launches of
+            # its own, and the 1x1 half only takes its zoomed result as a residual
+            if self._zoom_source(ln) is None or ln.inputs[0].shape[3] % 8 or A.inputs[0].shape[3] % 8:
+                return None
         if self._is_half_conv(ln) != self._is_half_conv(A):
             return None        # mixed mode: the two inputs would differ in type
         return A
