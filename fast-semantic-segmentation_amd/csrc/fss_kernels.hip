@@ -272,6 +272,25 @@ __global__ void add_act_kernel(const T* __restrict__ a, const T* __restrict__ b,
   va.store(y + idx * E);
 }
 
+// ------------------------------------------------------------- to half precision
+template <typename T>
+__global__ void to_half_kernel(const T* __restrict__ x, f16_t* __restrict__ y, size_t chunks) {
+  constexpr int E = Chunk<T>::N;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= chunks) return;
+  Chunk<T> v;
+  v.load(x + idx * E);
+  if constexpr (E == 8) {
+    Chunk<f16_t> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.v[e] = v.v[e];
+    o.store_nt(y + idx * 8);
+  } else {
+    *reinterpret_cast<uint2*>(y + idx * 4) =
+        make_uint2(Chunk<f16_t>::sat2(v.v[0], v.v[1]), Chunk<f16_t>::sat2(v.v[2], v.v[3]));
+  }
+}
+
 // ------------------------------------- x2 zoom behind a convolution (border pieces)
 // conv3x3 with dilation 2 of an align_corners x2 zoom equals the x2 zoom of the plain conv3x3
 // of the source, except on output rows / columns 1 and 2H-3 / 2W-3: there one of the two
@@ -1309,6 +1328,25 @@ int fss_add_act(const void* a, const void* b, void* y, size_t count, int act, in
   else
     hipLaunchKernelGGL(add_act_kernel<bf16_t>, dim3(grid_for(chunks)), dim3(kBlock), 0, s,
                        (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, chunks, act);
+  FSS_LAUNCH_CHECK();
+  return 0;
+}
+
+int fss_to_half(const void* x, void* y, size_t count, int dtype, void* stream) {
+  FSS_REQUIRE(x && y, "null argument");
+  FSS_REQUIRE(dtype == FSS_F32 || dtype == FSS_F32_BF16X3, "dtype must be FSS_F32 or FSS_F32_BF16X3");
+  const int e = chunk_of(dtype);
+  FSS_REQUIRE(count > 0 && count % e == 0, "count must be a multiple of the channel group");
+  FSS_ALIGNED(x);
+  FSS_REQUIRE(((uintptr_t)y & (e == 8 ? 15 : 7)) == 0, "unaligned pointer");
+  const size_t chunks = count / e;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == FSS_F32)
+    hipLaunchKernelGGL(to_half_kernel<float>, dim3(grid_for(chunks)), dim3(kBlock), 0, s,
+                       (const float*)x, (f16_t*)y, chunks);
+  else
+    hipLaunchKernelGGL(to_half_kernel<f32s_t>, dim3(grid_for(chunks)), dim3(kBlock), 0, s,
+                       (const f32s_t*)x, (f16_t*)y, chunks);
   FSS_LAUNCH_CHECK();
   return 0;
 }

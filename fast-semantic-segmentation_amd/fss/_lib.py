@@ -90,6 +90,7 @@ PROTOTYPES = {
     'fss_pyramid_add_nhwc': (c_int, [c_void_p, ctypes.POINTER(c_void_p), c_int_p, c_int_p,
                                      c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     'fss_add_act': (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    'fss_to_half': (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     'fss_copy_channels': (c_int, [c_void_p, c_int, c_void_p, c_int, c_size_t, c_int, c_int, c_void_p]),
     'fss_preprocess_u8': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_float_p, c_float_p, c_int, c_void_p]),

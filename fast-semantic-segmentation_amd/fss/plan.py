@@ -245,9 +245,7 @@ class CompiledGraph(ConvLowering, ConvTuning, Schedule):
         scope = a['weights'].rsplit('/', 1)[0]
         if not any(r.search(scope) for r in self.half_act_re):
             return False
-        if ((a['kh'], a['kw'], a['stride'], a['rate'], a['pad_top'], a['pad_left']) != (1, 1, 1, 1, 0, 0)
-                or a['biases'] is not None or ln.inputs[0].shape[3] % 8 or ln.shape[3] % 8
-                or ln.shape[:3] != ln.inputs[0].shape[:3]):
+        if a['biases'] is not None or ln.inputs[0].shape[3] % 8 or ln.shape[3] % 8:
             return False
         if not self.fuse_dual:
             return True
@@ -261,8 +259,9 @@ class CompiledGraph(ConvLowering, ConvTuning, Schedule):
                     mate = other
         if mate is None:
             return ln not in self.dual
-        if ln.inputs[0].shape[3] % 64:
-            return False    # a shared launch takes whole K tiles of both inputs
+        if (ln.inputs[0].shape[3] % 64 or (a['kh'], a['kw'], a['stride'], a['rate']) != (1, 1, 1, 1)
+                or ln.shape[:3] != ln.inputs[0].shape[:3]):
+            return False    # a shared launch: 1x1, whole K tiles of both inputs
         if mate.pos < ln.pos and self._zoom_source(mate) is not None:
             return True     # the mate runs in front of its zoom, in launches of its own
         ms = mate.attrs['weights'].rsplit('/', 1)[0]

@@ -39,9 +39,13 @@ DEFAULT_HALF_SCOPES = (r'/bottleneck_v1/conv2$', r'^Conv(_[123])?$')
 # branch in front of the last fusion (2.29e-4).  In MobileNetV2 the projection of an inverted
 # residual (third_party/conv_blocks.py:290-300) reads the depthwise output this way, and the
 # expanded tensors on both sides of the depthwise convolution - internal to the unit, six times
-# as wide as its input - are half precision (ICNet-MobileNetV2: 3.51e-4 -> 3.71e-4).
+# as wide as its input - are half precision (ICNet-MobileNetV2: 3.51e-4 -> 3.71e-4).  The 3x3
+# convolution over PSPNet's 4096-channel concatenation (architectures/pspnet_architecture.py:144)
+# is two fifths of that model's time at three MFMAs per product: its input is converted to half
+# precision in a pass of its own, which a K axis of 36864 repays (PSPNet: 2.25e-4 -> 2.75e-4).
 DEFAULT_HALF_ACT_SCOPES = (r'/bottleneck_v1/conv3$', r'/block1/unit_1/bottleneck_v1/(conv1|shortcut)$',
-                           r'^CascadeFeatureFusion(_\d+)?/Conv$', r'/expanded_conv(_\d+)?/project$')
+                           r'^CascadeFeatureFusion(_\d+)?/Conv$', r'/expanded_conv(_\d+)?/project$',
+                           r'^PSPModule/Conv_\d+$')
 
 
 class LNode(object):
@@ -99,6 +103,6 @@ _OUT_ARGS = {
     'fss_conv2d_dual_head_nhwc': (13,), 'fss_zoom2_border_gather': (1, 2, 3), 'fss_zoom2_conv_commute': (4,),
     'fss_dwconv2d_nhwc': (3,), 'fss_subsample_nhwc': (1,), 'fss_maxpool_nhwc': (1,),
     'fss_avgpool_bins_nhwc': (1,), 'fss_avgpool_pyramid_nhwc': (1, 7), 'fss_resize_bilinear_nhwc': (1,), 'fss_pyramid_add_nhwc': (5,),
-    'fss_add_act': (2,), 'fss_copy_channels': (2,), 'fss_upsample_argmax': (1, 2),
+    'fss_add_act': (2,), 'fss_to_half': (1,), 'fss_copy_channels': (2,), 'fss_upsample_argmax': (1, 2),
     'fss_label_lut': (1,),
 }

@@ -580,6 +580,15 @@ class ConvLowering(object):
         n, h, w, cin = x.shape
         _, ho, wo, cout = ln.shape
         kh, kw = a['kh'], a['kw']
+        if (x.dt == 'f32s' and x.dense and x.phys_c == cin and kh * kw * cin >= 8192
+                and self._takes_half_acts(ln)):
+            # a long K axis repays a pass that rounds the input to half precision: two MFMAs per
+            # product (two-f16 weights) instead of three
+            xh = Val(self._alloc(x.shape, 'f16'), x.shape, 'f16')
+            self.temps.append(xh)
+            self._emit('copy', a['weights'].rsplit('/', 1)[0] + '/to_half', 'fss_to_half',
+                       (x.ptr, xh.ptr, n * h * w * cin, _CODE[x.dt], self.sh), nbytes=n * h * w * cin * 6)
+            x = xh
         in_dt = x.dt
         act = a['activation']
         res, result = None, ln
@@ -644,16 +653,17 @@ class ConvLowering(object):
             self.vals[result] = out
             if result is not ln:
                 self.vals[ln] = out
-            d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=1, kw=1, stride=1, dilation=1, pad_top=0,
-                              pad_left=0, ho=ho, wo=wo, act=_lib.ACT_CODES[act], in_dtype=_lib.F16_W2,
+            d = _lib.ConvDesc(n=n, h=h, w=w, cin=cin, cout=cout, kh=kh, kw=kw, stride=a['stride'],
+                              dilation=a['rate'], pad_top=a['pad_top'], pad_left=a['pad_left'], ho=ho, wo=wo,
+                              act=_lib.ACT_CODES[act], in_dtype=_lib.F16_W2,
                               out_dtype=_CODE[out_dt], y_ld=out.ld, res_ld=res.ld if res else 0,
                               k_pad=k_pad, cout_pad=cout_pad)
-            nbytes = ((n * h * w * cin + 2 * cout * cin) * 2 + n * ho * wo * cout * _ESZ[out_dt]
+            nbytes = ((n * h * w * cin + 2 * cout * kh * kw * cin) * 2 + n * ho * wo * cout * _ESZ[out_dt]
                       + (n * ho * wo * cout * _ESZ[res.dt] if res else 0))
             self._emit('conv', a['weights'].rsplit('/', 1)[0], 'fss_conv2d_nhwc',
                        (ctypes.byref(d), x.ptr, self._pack(Wp, 'f16w').data_ptr(), bdev.data_ptr(),
                         res.ptr if res else None, out.ptr, self.sh),
-                       flops=2 * n * ho * wo * cout * cin, nbytes=nbytes, keep=d, mpp=2)
+                       flops=2 * n * ho * wo * cout * kh * kw * cin, nbytes=nbytes, keep=d, mpp=2)
             return
         head = None
         if res is None and a['biases'] is None and pc == cin and cin % 64 == 0 and a['stride'] == 1:

@@ -339,6 +339,13 @@ int fss_pyramid_add_nhwc(const void* x, const void* const* p, const int* bh,
 int fss_add_act(const void* a, const void* b, void* y, size_t count, int act,
                 int dtype, void* stream);
 
+/* y = x rounded to FSS_F16 (to nearest even, saturating), elementwise over `count` elements of
+ * a dense FSS_F32 or FSS_F32_BF16X3 tensor.  The storage conversion in front of a convolution
+ * that reads half-precision activations against two-f16 weights (in_dtype FSS_F16_W2) when its
+ * input exists only at float quality and its K axis is long enough to repay the pass: the 3x3
+ * convolution over the 4096-channel concatenation of architectures/pspnet_architecture.py:143-147. */
+int fss_to_half(const void* x, void* y, size_t count, int dtype, void* stream);
+
 /* Copies a [pixels, c] tensor into / out of a wider one (channel concat).
  * Replaces tf.concat(axis=-1) (architectures/pspnet_architecture.py:143). */
 int fss_copy_channels(const void* x, int x_ld, void* y, int y_ld, size_t pixels,
