@@ -105,7 +105,8 @@ class ConvTuning(object):
             # per CU) under a long K axis, i.e. the late backbone blocks at one or two frames
             m_rows = d.n * d.ho * d.wo
             ksplits = ()
-            if (fname == 'fss_conv2d_nhwc' and self.ksplit and m_rows * d.cout <= 64 * 64 * 256 * 4
+            if (fname == 'fss_conv2d_nhwc' and self.ksplit and d.in_dtype != _lib.F16_W2
+                    and m_rows * d.cout <= 64 * 64 * 256 * 4
                     and d.kh * d.kw * d.cin >= 1024):
                 ksplits = (2, 4, 8)
             if fname == 'fss_conv2d_dual_nhwc':
