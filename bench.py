@@ -43,7 +43,8 @@ PAD_SHAPE = (1025, 2049)
 # product, which `mfma_issue_frac` prices.
 PEAK_TFLOPS = {'bfloat16': 2500.0, 'float32': 157.3, 'float32x3': 2500.0, 'mixed': 2500.0}
 DTYPE_TAG = {'bfloat16': 'bf16', 'float32': 'f32', 'float32x3': 'f32 (bf16x3 products)',
-             'mixed': 'f32 (bf16x3 products) + f16 (3x3 convolutions of the bottleneck units, full-resolution branch)'}
+             'mixed': 'f32 as split-bf16 (three MFMAs per product) + f16 (3x3 convolutions of the bottleneck units, '
+                      'full-resolution branch) + f16 activations x two-f16 weights (conv3, stem, first unit, last fusion)'}
 CONV_KINDS = ('conv', 'conv3x3', 'stem2', 'stem', 'chain')
 
 # the other model configurations of the path: name -> (config file, frame shape, padded size,
@@ -232,10 +233,12 @@ def roofline_of(prof, dtype, batch):
         # algorithmic FLOP (every product once) of the launches over their time
         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
         # the same launches priced with the MFMA instructions they issue (three per product in the
-        # split-bf16 launches, one in the half-precision / bf16 ones)
+        # split-bf16 launches, two with two-f16 weights, one in the half-precision / bf16 ones)
         'mfma_issue_tflops': issued / (conv_ms * 1e-3) / 1e12,
         'mfma_issue_frac': issued / (conv_ms * 1e-3) / 1e12 / peak,
         'split_bf16_share_of_flop': sum(p['flops'] for p in conv if p['mfma_per_product'] == 3) / max(conv_flops, 1),
+        # ... and of the launches with half-precision activations against two-f16 weights (two MFMAs)
+        'two_f16_weight_share_of_flop': sum(p['flops'] for p in conv if p['mfma_per_product'] == 2) / max(conv_flops, 1),
         'traffic': measured_conv_traffic(batch, n_conv, dtype),
         'algorithmic_bytes': sum(p['bytes'] for p in conv) / n_conv,
         'launches_per_step': n_conv,
