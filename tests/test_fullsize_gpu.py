@@ -196,3 +196,32 @@ def test_other_configurations_at_their_stated_batch(name):
         agree = float((labels[f, ..., 0] == ref[0]).mean())
         print('%s frame %d of %d: argmax agreement %.5f' % (name, f, b, agree))
         assert agree >= 0.999
+
+
+def test_headline_plan_takes_the_intended_routes():
+    """The plan bench.py times by default (mixed mode, its default frames per launch): every
+    layer shape comes from the shipped tuning table (a stale table would be ignored silently and
+    every plan build would time its candidates), and the precision routes of the mode are the
+    ones taken - two-f16-weight launches for conv3 of the bottleneck units, the first unit and the
+    classifier launch, the raw-byte stem with half-precision output, a half-precision max-pool -
+    on a fraction of the memory a buffer per tensor would take."""
+    import re
+    import bench
+    from fss import _lib
+    # bench.py's own default
+    batch = int(re.search(r"'--batch', type=int, default=(\d+)", open(bench.__file__).read()).group(1))
+    cg, pred, _, _ = bench.build_plan(batch, 'mixed')
+    assert cg.tuned_now == 0, '%d layer shapes were not in fss/conv_tuned.json' % cg.tuned_now
+    descs = [(s.keep[0] if isinstance(s.keep, tuple) else s.keep) for s in cg.steps]
+    wide = [d for d in descs if isinstance(d, _lib.ConvDesc) and d.in_dtype == _lib.F16_W2]
+    assert len(wide) >= 14
+    fn = dict(zip(cg.step_fname, cg.steps))
+    assert fn['fss_conv2d_dual_head_nhwc'].keep[0].in_dtype == _lib.F16_W2
+    assert fn['fss_stem_conv_u8'].args[22] == _lib.F16_W2
+    assert fn['fss_maxpool_nhwc'].args[12] == _lib.F16
+    assert 0 < cg.activation_bytes < 0.6 * cg.activation_bytes_unshared
+    del cg
+    for dtype in ('bfloat16', 'float32x3'):
+        cg, _, _, _ = bench.build_plan(batch, dtype)
+        assert cg.tuned_now == 0, dtype
+        del cg
