@@ -116,10 +116,13 @@ typedef struct fss_conv_desc {
   int32_t ho, wo;            /* output spatial size                        */
   int32_t act;               /* FSS_ACT_*                                  */
   int32_t in_dtype;          /* FSS_F32 | FSS_BF16 | FSS_F16 | FSS_F32_BF16X3
-                                (x, weights, residual)                      */
-  int32_t out_dtype;         /* FSS_F32 (any input) | FSS_BF16 (bf16 input) |
-                                FSS_F16 or FSS_F32_BF16X3 (FSS_F16 or
-                                FSS_F32_BF16X3 input)                       */
+                                (x, weights, residual), or FSS_F16_W2
+                                (FSS_F16 x, two-f16 weights, residual of
+                                the output's type)                          */
+  int32_t out_dtype;         /* FSS_F32 (any input but FSS_F16_W2) |
+                                FSS_BF16 (bf16 input) |
+                                FSS_F16 or FSS_F32_BF16X3 (FSS_F16,
+                                FSS_F16_W2 or FSS_F32_BF16X3 input)         */
   int32_t y_ld;              /* output pixel stride in elements (>= cout)  */
   int32_t res_ld;            /* residual pixel stride in elements          */
   int32_t k_pad, cout_pad;   /* packed weight dims                         */
