@@ -73,6 +73,8 @@ PROTOTYPES = {
                                        c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                        c_int, c_void_p, c_int, c_int, ctypes.c_longlong, c_int, c_void_p]),
     'fss_conv3x3_c64_nhwc': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 13 + [c_void_p]),
+    'fss_conv3x3_c128_pack_index': (c_int, [c_int_p]),
+    'fss_conv3x3_c128_nhwc': (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     'fss_zoom2_border_gather': (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     'fss_zoom2_conv_commute': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     'fss_stem_pack_dims': (c_int, [c_int, c_int, c_int, c_int, c_int_p, c_int_p]),
@@ -130,6 +132,22 @@ def check(status, what=''):
 
 def call(name, *args):
     check(getattr(lib, name)(*args), name)
+
+
+CONV3X3_C128_IMAGE_ELEMS = 294912
+_c128_index = None
+
+
+def conv3x3_c128_index():
+    """[294912, 2] int32: (row, k) of fss_conv2d_nhwc's packed [256][1152] matrix behind every element
+    of the filter image fss_conv3x3_c128_nhwc reads."""
+    global _c128_index
+    if _c128_index is None:
+        import numpy as np
+        idx = np.empty((CONV3X3_C128_IMAGE_ELEMS, 2), np.int32)
+        call('fss_conv3x3_c128_pack_index', idx.ctypes.data_as(c_int_p))
+        _c128_index = idx
+    return _c128_index
 
 
 def conv_pack_dims(cin, kh, kw, cout, dtype):

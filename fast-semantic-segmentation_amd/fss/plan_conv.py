@@ -646,6 +646,25 @@ class ConvLowering(object):
                        flops=2 * n * ho * wo * cout * 9 * cin,
                        nbytes=(n * h * w * cin + n * ho * wo * cout + cout * 9 * cin) * 2)
             return
+        if (self.resident_3x3 and (kh, kw, a['stride'], a['rate'], a['pad_top'], a['pad_left']) == (3, 3, 1, 1, 1, 1)
+                and pc == cin == 128 and cout == 256 and (ho, wo) == (h, w) and in_dt in ('bf16', 'f16')
+                and out_dt == in_dt and res is None and a['biases'] is None and k_pad == 9 * 128
+                and x.ld % 8 == 0 and h * w * x.ld * 2 < 2 ** 31 - 1):
+            # 128 -> 256 channels at stride 1 (`Conv_3`): persistent blocks, the input tile and its
+            # halo in LDS for all nine taps, the filter streamed as ready-made LDS images (measured
+            # 3.33 against 3.93 ms for the best implicit-GEMM tile at 192 frames; same bits)
+            idx = _lib.conv3x3_c128_index().astype(np.int64)
+            flat = torch.from_numpy(idx[:, 0] * k_pad + idx[:, 1]).to(self.device)
+            wimg = wdev.flatten()[flat].contiguous()
+            self.keepalive.append(wimg)
+            out = Val(self._alloc(ln.shape, out_dt), ln.shape, out_dt)
+            self.vals[result] = out
+            self._emit('conv3x3', a['weights'].rsplit('/', 1)[0], 'fss_conv3x3_c128_nhwc',
+                       (x.ptr, x.ld, wimg.data_ptr(), bdev.data_ptr(), out.ptr, out.ld, n, h, w,
+                        _lib.ACT_CODES[act], _CODE[in_dt], self.sh),
+                       flops=2 * n * ho * wo * cout * 9 * cin,
+                       nbytes=(n * h * w * cin + n * ho * wo * cout + cout * 9 * cin) * 2)
+            return
         if in_dt == 'f16' and pc == cin and self._takes_half_acts(ln):
             # half-precision activations, float-quality weights (FSS_F16_W2): per output channel
             # the k_pad high parts f16(W), then the k_pad remainders f16(W - high)

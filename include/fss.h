@@ -240,6 +240,23 @@ int fss_conv3x3_c64_nhwc(const void* x, int x_ld, const void* w, const float* bi
                          int y_ld, int n, int h, int wd, int ho, int wo, int cout, int stride,
                          int dilation, int pad_top, int pad_left, int act, int dtype, void* stream);
 
+/* 3x3 convolution, stride 1, dilation 1, one pixel of zero padding all round, 128 -> 256
+ * channels (FSS_BF16 or FSS_F16), with the input tile and its halo resident in LDS:
+ *   y[n,h,wd,256] = act(conv3x3(x[n,h,wd,128], w) + bias)
+ * `Conv_3` of the full-resolution branch (architectures/icnet_architecture.py:223-225).  Persistent
+ * blocks; every input pixel goes through the global -> LDS path once per tile instead of once per
+ * tap, the filter streams through a ring that does not stop between tiles, the results leave
+ * the accumulators as 16-byte stores.  Bit-identical to fss_conv2d_nhwc on the same operands
+ * (same MFMA, same order along k).  w_image: the filter as the kernel's LDS image, 294912
+ * 16-bit elements; element e is W[index[2e]][index[2e+1]] of fss_conv2d_nhwc's packed matrix
+ * ([256][1152], k = (r*3 + s)*128 + c, batch norm folded in) with `index` from
+ * fss_conv3x3_c128_pack_index (2 * 294912 entries).  bias: float [256] or NULL; x_ld / y_ld: pixel
+ * strides in elements (multiples of 8, at least 128 / 256); a frame of x is less than 2 GiB. */
+#define FSS_CONV3X3_C128_IMAGE_ELEMS 294912
+int fss_conv3x3_c128_pack_index(int32_t* index);
+int fss_conv3x3_c128_nhwc(const void* x, int x_ld, const void* w_image, const float* bias, void* y,
+                          int y_ld, int n, int h, int wd, int act, int dtype, void* stream);
+
 /* Pieces of  conv3x3_dilation2(zoom_x2(x)) = zoom_x2(conv3x3(x))  (align_corners zoom to
  * (2h-1, 2w-1), zero padding, both sides linear in x), which holds everywhere except on
  * output rows / columns 1 and 2h-3 / 2w-3: there one of the source results that the zoom

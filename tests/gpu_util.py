@@ -263,6 +263,36 @@ def conv3x3_c64(x, w, bias, stride, rate, pads, out_hw, act, y_ld=None, dt='bf16
     return out[..., :cout]
 
 
+def conv3x3_c128_image(w, dt):
+    """[3,3,128,256] filter -> device tensor holding the LDS image fss_conv3x3_c128_nhwc streams."""
+    bits = half_bits(np.ascontiguousarray(w.transpose(3, 0, 1, 2).reshape(256, -1)), dt)
+    idx = _lib.conv3x3_c128_index()
+    return torch.from_numpy(np.ascontiguousarray(bits[idx[:, 0], idx[:, 1]]).view(np.int16)).cuda()
+
+
+def conv3x3_c128(x, w, bias, act, y_ld=None, x_ld=None, dt='f16'):
+    """act(conv3x3(x, w) + bias), stride 1, SAME, through fss_conv3x3_c128_nhwc (input tile + halo in
+    LDS).  x: [n,h,w,128]; w: [3,3,128,256].  Returns float32 [n,h,w,256]."""
+    n, h, wd, cin = x.shape
+    wdev = conv3x3_c128_image(w, dt)
+    xd = to_dev(x, dt)
+    if x_ld and x_ld != cin:
+        wide = torch.full((n, h, wd, x_ld), 3.0, dtype=DT[dt][1], device='cuda')
+        wide[..., :cin] = xd
+        xd = wide
+    bd = torch.from_numpy(np.asarray(bias, np.float32)).cuda() if bias is not None else None
+    ld = y_ld or 256
+    y = torch.full((n, h, wd, ld), -77.0, dtype=DT[dt][1], device='cuda')
+    torch.cuda.synchronize()
+    _lib.call('fss_conv3x3_c128_nhwc', xd.data_ptr(), xd.shape[3], wdev.data_ptr(),
+              bd.data_ptr() if bd is not None else None, y.data_ptr(), ld, n, h, wd, _lib.ACT_CODES[act],
+              DT[dt][0], None)
+    _lib.call('fss_device_sync')
+    out = to_host(y)
+    assert np.all(out[..., 256:] == -77.0), 'wrote outside its channels'
+    return out[..., :256]
+
+
 def zoomed_dilated_conv(x, w, dt='f32'):
     """conv3x3 with dilation 2 (SAME) of the align_corners x2 zoom of x, computed at the source
     resolution: fss_zoom2_border_gather, four fss_conv2d_nhwc launches (x and the three crop

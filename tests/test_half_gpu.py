@@ -290,3 +290,25 @@ def test_stem_conv_u8_raw_bytes_half_output(k, stride, cout, sub):
     ref = O.relu6(O.conv2d(img, w, stride, 1, (pt, pb, pl, pr), np.float64) + bias)
     got = gu.stem_conv(frames, w, bias, mean, scale, sub, (hl, wl), stride, 1, (pt, pl), (ho, wo), 'relu6', 'f16w')
     _close(got, ref, 1.0 / 1024, 'raw-byte stem, half output')
+
+
+@pytest.mark.parametrize('n,h,wd,dt,act', [
+    (2, 9, 70, 'f16', 'relu6'),       # one full band, a ragged band of 6 columns, a 1-row last tile
+    (1, 13, 129, 'f16', 'relu'),      # two bands and a single-column band (one tall tile)
+    (3, 6, 37, 'bf16', 'relu6'),      # ragged band only
+    (2, 8, 64, 'f16', None),          # no ragged band
+    (1, 129, 65, 'f16', 'relu6'),     # the real height: 33 row tiles and the 129-row column tile
+    (5, 21, 257, 'bf16', 'relu'),     # the real width, more tiles than fit one round of some grids
+])
+def test_conv3x3_c128_matches_implicit_gemm(n, h, wd, dt, act):
+    """fss_conv3x3_c128_nhwc (persistent blocks, input tile + halo in LDS) gives the bits of fss_conv2d_nhwc
+    on the same operands: regular tiles, ragged right-hand bands, partial last tiles, wide pixel strides."""
+    gu = _gu()
+    rng = np.random.RandomState(n * 1000 + h * 10 + wd)
+    x = rng.randn(n, h, wd, 128).astype(np.float32)
+    w = (rng.randn(3, 3, 128, 256) * 0.03).astype(np.float32)
+    bias = rng.randn(256).astype(np.float32)
+    ref = gu.conv2d(x, w, bias, None, 1, 1, (1, 1), (h, wd), act, dt=dt)
+    out = gu.conv3x3_c128(x, w, bias, act, y_ld=256 + 8, x_ld=128 + 16 if wd == 70 else None, dt=dt)
+    assert out.shape == ref.shape
+    assert np.array_equal(out, ref), np.abs(out - ref).max()
