@@ -526,6 +526,20 @@ def test_entry_points_reject_bad_arguments():
     assert 'pixel strides' in c3(x_ld=60)
     assert 'unaligned' in c3(x=x.data_ptr() + 2)
     assert 'bad act' in c3(act=9)
+    # the 128 -> 256 channel 3x3 convolution with its input tile in LDS
+
+    def c128(**kw):
+        a = dict(x=x.data_ptr(), x_ld=128, w=w.data_ptr(), bias=None, y=y1.data_ptr(), y_ld=256, n=1, h=4, wd=8,
+                 act=1, dtype=L.F16)
+        a.update(kw)
+        return rejected('fss_conv3x3_c128_nhwc', *a.values(), None)
+    assert 'null' in c128(w=None)
+    assert 'bfloat16 and half' in c128(dtype=L.F32)
+    assert 'pixel strides' in c128(x_ld=64)
+    assert 'pixel strides' in c128(y_ld=250)
+    assert 'unaligned' in c128(y=y1.data_ptr() + 2)
+    assert 'bad act' in c128(act=9)
+    assert 'bad shape' in c128(h=0)
     L.call('fss_device_sync')
 
 
