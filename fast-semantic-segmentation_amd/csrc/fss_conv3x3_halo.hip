@@ -94,15 +94,6 @@ __device__ __forceinline__ HaloTile halo_tile_of(const HaloArgs& a, int t) {
 // whatever the tap's shift.
 __device__ __forceinline__ int halo_window(int p, int c) { return c ^ ((p & 7) << 1); }
 
-// f(integral_constant<int, I>) for I = FIRST .. LAST - 1, in order
-template <int FIRST, int LAST, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (FIRST < LAST) {
-    f(std::integral_constant<int, FIRST>{});
-    static_for<FIRST + 1, LAST>(f);
-  }
-}
-
 template <typename H>
 __global__ void __launch_bounds__(kHThreads) conv3x3_c128_halo_kernel(const HaloArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

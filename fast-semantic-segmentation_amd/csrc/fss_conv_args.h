@@ -1,5 +1,7 @@
 // Argument block and LDS-DMA helpers shared by the convolution kernels.
 #pragma once
+#include <type_traits>
+
 #include "fss_common.h"
 
 namespace fss {
@@ -87,6 +89,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+
+// f(integral_constant<int, I>) for I = FIRST .. LAST - 1, in order
+template <int FIRST, int LAST, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (FIRST < LAST) {
+    f(std::integral_constant<int, FIRST>{});
+    static_for<FIRST + 1, LAST>(f);
+  }
+}
 
 // The 256x256, 8-wave, 8-phase form of the bf16 convolution (fss_conv8.hip).  Returns -1 when the
 // layer is outside what it covers (the caller then uses another configuration of the same MFMA
