@@ -573,111 +573,8 @@ conv_igemm_kernel(const ConvArgs a) {
         b0 = *reinterpret_cast<const float4*>(a.bias + c0 + 8 * lg);
         b1 = *reinterpret_cast<const float4*>(a.bias + c0 + 8 * lg + 4);
       }
-      // Pixel groups whose interpolation sources are requested together (float sources): with 8
-      // waves per block there are registers for two groups' worth (64), and every batch is one
-      // exposure to the L2 latency instead of one per group; the 16-wave configurations have none
-      // to spare.
-      constexpr int ZPRE = (SPLIT && NT <= 512 && MI % 2 == 0) ? 2 : 1;
 #pragma unroll
-      for (int i0 = 0; i0 < MI; i0 += ZPRE) {
-      float zres[ZPRE][8];
-      if constexpr (SPLIT) {
-        if (a.zy != nullptr) {
-          const char* src[ZPRE][4];
-          bool two[ZPRE];
-#pragma unroll
-          for (int ii = 0; ii < ZPRE; ++ii) {
-            const int i = i0 + ii;
-            // float sources (32 bytes per 8 channels): the addresses of the (up to) four sources
-            const unsigned zbase = (zo[i] & ~15u) + (unsigned)(32 * s) * ESZ;
-            const unsigned zdr = (zo[i] & 1u) ? zrow : 0u, zdc = (zo[i] & 2u) ? zpix : 0u;
-            two[ii] = zeven[i] && !zborder[i];
-            if (!zborder[i]) {
-#pragma unroll
-              for (int nb = 0; nb < 4; ++nb)
-                src[ii][nb] = zyb + (zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u));
-            } else {
-              // next to the frame border a source row / column is replaced by its corrected copy
-              const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
-              const int f = m / HoWo, rem = m - f * HoWo;
-              const int p = rem / a.Wo, q = rem - p * a.Wo;
-              const unsigned lane_c = (unsigned)(c0 + 8 * lg) * ESZ;
-#pragma unroll
-              for (int nb = 0; nb < 4; ++nb) {
-                const int zi = (p >> 1) + ((nb >> 1) & p), zj = (q >> 1) + (nb & q & 1);
-                const int rf = (p == 1 && zi == 1) ? 1 : (p == a.Ho - 2 && zi == a.zH - 2) ? 2 : 0;
-                const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
-                const char* base = zyb;
-                unsigned off = zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u);
-                if (rf != 0 && cf == 0) {
-                  base = reinterpret_cast<const char*>(a.zytb);
-                  off = (unsigned)(((rf - 1) * a.N + f) * a.zW + zj) * zpix + lane_c;
-                }
-                if (rf == 0 && cf != 0) {
-                  base = reinterpret_cast<const char*>(a.zylr);
-                  off = (unsigned)(((cf - 1) * a.N + f) * a.zH + zi) * zpix + lane_c;
-                }
-                if (rf != 0 && cf != 0) {
-                  base = reinterpret_cast<const char*>(a.zycn);
-                  off = (unsigned)(((rf - 1) * 2 + (cf - 1)) * a.N + f) * zpix + lane_c;
-                }
-                src[ii][nb] = base + off;
-              }
-            }
-          }
-          // the sources are plain floats here (nothing else reads them, so their producer skips
-          // the split): 8 channels = two 16-byte loads per source
-          if constexpr (ZPRE == 1) {
-            // ... summed as they arrive
-            const float zsc = two[0] ? 0.5f : 0.25f;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-              const float4 t0 = *reinterpret_cast<const float4*>(src[0][0] + 16 * hh);
-              const float4 t1 = *reinterpret_cast<const float4*>(src[0][1] + 16 * hh);
-              float4 t = make_float4(t0.x + t1.x, t0.y + t1.y, t0.z + t1.z, t0.w + t1.w);
-              if (!two[0]) {
-                const float4 t2 = *reinterpret_cast<const float4*>(src[0][2] + 16 * hh);
-                const float4 t3 = *reinterpret_cast<const float4*>(src[0][3] + 16 * hh);
-                t.x += t2.x + t3.x; t.y += t2.y + t3.y; t.z += t2.z + t3.z; t.w += t2.w + t3.w;
-              }
-              zres[0][4 * hh] = t.x * zsc; zres[0][4 * hh + 1] = t.y * zsc;
-              zres[0][4 * hh + 2] = t.z * zsc; zres[0][4 * hh + 3] = t.w * zsc;
-            }
-          } else {
-            // ... all requested before any is used
-            float4 zt[ZPRE][2][4];
-#pragma unroll
-            for (int ii = 0; ii < ZPRE; ++ii)
-#pragma unroll
-              for (int hh = 0; hh < 2; ++hh) {
-                zt[ii][hh][0] = *reinterpret_cast<const float4*>(src[ii][0] + 16 * hh);
-                zt[ii][hh][1] = *reinterpret_cast<const float4*>(src[ii][1] + 16 * hh);
-                if (!two[ii]) {
-                  zt[ii][hh][2] = *reinterpret_cast<const float4*>(src[ii][2] + 16 * hh);
-                  zt[ii][hh][3] = *reinterpret_cast<const float4*>(src[ii][3] + 16 * hh);
-                }
-              }
-#pragma unroll
-            for (int ii = 0; ii < ZPRE; ++ii) {
-              const float zsc = two[ii] ? 0.5f : 0.25f;
-#pragma unroll
-              for (int hh = 0; hh < 2; ++hh) {
-                const float4 t0 = zt[ii][hh][0], t1 = zt[ii][hh][1];
-                float4 t = make_float4(t0.x + t1.x, t0.y + t1.y, t0.z + t1.z, t0.w + t1.w);
-                if (!two[ii]) {
-                  const float4 t2 = zt[ii][hh][2], t3 = zt[ii][hh][3];
-                  t.x += t2.x + t3.x; t.y += t2.y + t3.y; t.z += t2.z + t3.z; t.w += t2.w + t3.w;
-                }
-                zres[ii][4 * hh] = t.x * zsc; zres[ii][4 * hh + 1] = t.y * zsc;
-                zres[ii][4 * hh + 2] = t.z * zsc; zres[ii][4 * hh + 3] = t.w * zsc;
-              }
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int ii = 0; ii < ZPRE; ++ii) {
-        const int i = i0 + ii;
+      for (int i = 0; i < MI; ++i) {
         f32x4 d0 = acc[i][2 * s], d1 = acc[i][2 * s + 1];
         if (a.zy != nullptr) {
           // residual = corrected x2 zoom of zy at this lane's pixel: the mean of 1, 2 or 4
@@ -745,8 +642,62 @@ conv_igemm_kernel(const ConvArgs a) {
               for (int e = 0; e < 4; ++e) { d0[e] += r0[e] * 0.25f; d1[e] += r1[e] * 0.25f; }
             }
           } else {
+            // float sources (32 bytes per 8 channels): the addresses of the (up to) four sources
+            // first
+            const unsigned zbase = (zo[i] & ~15u) + (unsigned)(32 * s) * ESZ;
+            const unsigned zdr = (zo[i] & 1u) ? zrow : 0u, zdc = (zo[i] & 2u) ? zpix : 0u;
+            const bool two = zeven[i] && !zborder[i];
+            const char* src[4];
+            if (!zborder[i]) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { d0[e] += zres[ii][e]; d1[e] += zres[ii][4 + e]; }
+              for (int nb = 0; nb < 4; ++nb)
+                src[nb] = zyb + (zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u));
+            } else {
+              // next to the frame border a source row / column is replaced by its corrected copy
+              const int m = min(tile_m * BM + wm * WTM + i * 16 + lrow, a.M - 1);
+              const int f = m / HoWo, rem = m - f * HoWo;
+              const int p = rem / a.Wo, q = rem - p * a.Wo;
+              const unsigned lane_c = (unsigned)(c0 + 8 * lg) * ESZ;
+#pragma unroll
+              for (int nb = 0; nb < 4; ++nb) {
+                const int zi = (p >> 1) + ((nb >> 1) & p), zj = (q >> 1) + (nb & q & 1);
+                const int rf = (p == 1 && zi == 1) ? 1 : (p == a.Ho - 2 && zi == a.zH - 2) ? 2 : 0;
+                const int cf = (q == 1 && zj == 1) ? 1 : (q == a.Wo - 2 && zj == a.zW - 2) ? 2 : 0;
+                const char* base = zyb;
+                unsigned off = zbase + ((nb & 2) ? zdr : 0u) + ((nb & 1) ? zdc : 0u);
+                if (rf != 0 && cf == 0) {
+                  base = reinterpret_cast<const char*>(a.zytb);
+                  off = (unsigned)(((rf - 1) * a.N + f) * a.zW + zj) * zpix + lane_c;
+                }
+                if (rf == 0 && cf != 0) {
+                  base = reinterpret_cast<const char*>(a.zylr);
+                  off = (unsigned)(((cf - 1) * a.N + f) * a.zH + zi) * zpix + lane_c;
+                }
+                if (rf != 0 && cf != 0) {
+                  base = reinterpret_cast<const char*>(a.zycn);
+                  off = (unsigned)(((rf - 1) * 2 + (cf - 1)) * a.N + f) * zpix + lane_c;
+                }
+                src[nb] = base + off;
+              }
+            }
+            // the sources are plain floats here (nothing else reads them, so their producer skips
+            // the split): 8 channels = two 16-byte loads per source, summed as they arrive
+            float r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+              const float4 t0 = *reinterpret_cast<const float4*>(src[0] + 16 * hh);
+              const float4 t1 = *reinterpret_cast<const float4*>(src[1] + 16 * hh);
+              float4 t = make_float4(t0.x + t1.x, t0.y + t1.y, t0.z + t1.z, t0.w + t1.w);
+              if (!two) {
+                const float4 t2 = *reinterpret_cast<const float4*>(src[2] + 16 * hh);
+                const float4 t3 = *reinterpret_cast<const float4*>(src[3] + 16 * hh);
+                t.x += t2.x + t3.x; t.y += t2.y + t3.y; t.z += t2.z + t3.z; t.w += t2.w + t3.w;
+              }
+              r8[4 * hh] = t.x; r8[4 * hh + 1] = t.y; r8[4 * hh + 2] = t.z; r8[4 * hh + 3] = t.w;
+            }
+            const float zsc = two ? 0.5f : 0.25f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d0[e] += r8[e] * zsc; d1[e] += r8[4 + e] * zsc; }
           }
         } else if (a.res != nullptr) {
           if constexpr (!SPLIT) {
@@ -783,7 +734,6 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) MMA::run(acc2[i][ct], wa[ct], fb);
         }
-      }
       }
     }
     // acc2[i][ct][q] = partial score of class 16 ct + 4 lg + q, pixel 16 i + lrow, over this
