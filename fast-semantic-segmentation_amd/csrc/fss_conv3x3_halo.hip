@@ -9,7 +9,7 @@
 // two blocks per CU at 128 x 256: twice the weight bytes through the global -> LDS path, which
 // bounds the loop) and stages every input byte nine times.  Here
 //   * a block is persistent and owns the CU; per tile of 4 x 64 output pixels (or a ragged band
-//     at the right edge, see tile_of) the 6 x 66 input pixels it needs are copied to LDS ONCE and
+//     at the right edge, see halo_tile_of) the 6 x 66 input pixels it needs are copied to LDS ONCE and
 //     all nine taps read them there at shifted addresses;
 //   * the filter streams through a ring of three 16 KiB stages (one tap, 32 input channels, all
 //     256 filters) that never stops at a tile boundary: the stages of a tile's first two steps are

@@ -292,6 +292,22 @@ def test_conv3x3_c64_matches_oracle(n, h, wd, cout, stride, rate, mode):
     _close(out, plain, 1.0 / 128, 'resident 3x3 vs implicit GEMM')
 
 
+@pytest.mark.parametrize('n,h,wd,dt', [(2, 9, 70, 'bf16'), (1, 13, 129, 'f16'), (1, 3, 3, 'f16')])
+def test_conv3x3_c128_matches_oracle(n, h, wd, dt):
+    """fss_conv3x3_c128_nhwc (persistent blocks, input tile and halo in LDS) against the oracle's
+    convolution in float64: a full band with a ragged one, the single-column band, a frame smaller
+    than the filter's reach."""
+    gu = _gu()
+    rng = np.random.default_rng(67)
+    rnd = gu.bf16_round if dt == 'bf16' else gu.f16_round
+    x = rnd(rng.normal(0, 1, (n, h, wd, 128)).astype(np.float32))
+    w = rnd(rng.normal(0, 0.03, (3, 3, 128, 256)).astype(np.float32))
+    bias = rng.normal(0, 1, 256).astype(np.float32)
+    ref = np.minimum(O.relu(_conv_ref(x, w, 1, 1, 'SAME') + bias), 6.0)
+    out = gu.conv3x3_c128(x, w, bias, 'relu6', y_ld=256 + 8, dt=dt)
+    _close(out, ref, 1.0 / 128 if dt == 'bf16' else 1.0 / 1024, 'halo 3x3')
+
+
 @pytest.mark.parametrize('cin,cin2,cout1,cout2,with_res,pixels', [
     (64, 0, 256, 64, True, (2, 19, 31)),       # ICNet-1.0 block1: conv3 + identity shortcut -> conv1
     (64, 64, 256, 64, False, (1, 9, 17)),      # ... conv3 + projection shortcut -> conv1
