@@ -251,6 +251,12 @@ def roofline_of(prof, dtype, batch):
         'graph_tflops': graph_flops / (conv_ms * 1e-3) / 1e12,
         # every convolution kernel of the step (implicit GEMM, LDS-resident 3x3, fused stem pair,
         # uint8 stem): algorithmic FLOP over their time
+        # the convolutions that run in kernels of their own (3x3 layers with the filter or the input
+        # tile resident in LDS, the stems): not in the figures above, in `all_conv_kernels` below
+        'other_conv_kernels': {k: {'ms_per_step': sum(p['mean_ms'] for p in allc if p['kind'] == k),
+                                   'tflops': sum(p['flops'] for p in allc if p['kind'] == k)
+                                   / max(sum(p['mean_ms'] for p in allc if p['kind'] == k), 1e-9) / 1e9}
+                               for k in sorted({p['kind'] for p in allc} - {'conv'})},
         'all_conv_kernels': {'ms_per_step': all_ms,
                              'gflop_per_frame': sum(p['flops'] for p in allc) / batch / 1e9,
                              'tflops': sum(p['flops'] for p in allc) / (all_ms * 1e-3) / 1e12,
